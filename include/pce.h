@@ -1,0 +1,178 @@
+/*
+ * pce.h -- C ABI of the MI355X prosody-extraction engine ("pce").
+ *
+ * Drop-in boundary for the prosody + alignment hot path of
+ * hi-paris/Prosody-Control-French-TTS.  The reference has no FFI of its own
+ * (its boundary is Python call signatures); every entry
+ * point below names the reference call it replaces.  Plain C: pointers and
+ * sizes only, no C++/torch types.  The library (libpce.so) is built by hipcc
+ * for gfx950 only and has NO CPU fallback: pce_create fails when no GPU is
+ * present.
+ *
+ * Conventions
+ *   - return value: 0 (PCE_OK) or a negative pce_status; text via pce_last_error.
+ *   - one context per process per GPU, not thread-safe, one call in flight.
+ *   - the caller owns every host buffer; the library owns device memory only.
+ *   - *_run calls only enqueue kernels on the context's HIP stream; *_fetch
+ *     calls synchronise that stream and copy results to host buffers.
+ *   - audio is 16-bit PCM, mono; clips are concatenated, clip i occupying
+ *     samples [offsets[i], offsets[i+1]) of the buffer.
+ *   - a slice addresses samples [begin, end) of one clip in clip coordinates;
+ *     indices outside [0, clip length) are "virtual" samples equal to zero,
+ *     which is what both Praat's Sound_extractPart and pydub's silence padding
+ *     produce.  Converting (t0, t1) seconds or ms to sample indices is host
+ *     logic (pydub / Praat rules) and lives in the Python shim.
+ */
+#ifndef PCE_H
+#define PCE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCE_API_VERSION 1
+
+typedef struct pce_ctx pce_ctx;
+
+enum pce_status {
+    PCE_OK = 0,
+    PCE_E_INVALID = -1,   /* bad argument                                  */
+    PCE_E_DEVICE = -2,    /* HIP runtime error (text in pce_last_error)    */
+    PCE_E_NOMEM = -3,     /* host or device allocation failed              */
+    PCE_E_STATE = -4,     /* call order violated (fetch before run, ...)   */
+    PCE_E_LIMIT = -5      /* input exceeds a documented engine limit       */
+};
+
+/* per-slice status codes written to int32 status arrays */
+enum pce_slice_status {
+    PCE_SLICE_OK = 0,
+    PCE_SLICE_TOO_SHORT = 1,  /* Praat would throw / pyloudnorm raises ValueError */
+    PCE_SLICE_EMPTY = 2       /* zero samples                                      */
+};
+
+typedef struct pce_slice {
+    int32_t clip;     /* index into the uploaded batch                               */
+    int32_t flags;    /* reserved, 0                                                 */
+    int64_t begin;    /* first sample (clip coordinates, may be < 0)                 */
+    int64_t end;      /* one past the last sample (may exceed the clip length)       */
+    double  x1;       /* time of sample `begin` in seconds (Praat Sound.x1); only
+                         the pitch analysis reads it                                 */
+} pce_slice;
+
+/* ---- context ---------------------------------------------------------- */
+
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream)
+ * or NULL for a private stream.  Returns NULL on failure with text in err. */
+pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen);
+void pce_destroy(pce_ctx *ctx);
+const char *pce_last_error(const pce_ctx *ctx);
+int pce_sync(pce_ctx *ctx);
+int pce_api_version(void);
+int pce_device_info(pce_ctx *ctx, char *name, size_t namelen, int32_t *compute_units, int64_t *hbm_bytes);
+
+/* ---- batch residency ---------------------------------------------------
+ * Replaces the per-call full-file decode of the reference closures
+ * (AudioSegment.from_file / parselmouth.Sound(path) in
+ * Code/audioPipeline.py:319,327,340,361): a batch is decoded once by the host,
+ * uploaded once and stays resident in HBM for every measurement. */
+int pce_upload_pcm_s16(pce_ctx *ctx, const int16_t *pcm, const int64_t *offsets, int32_t n_clips, int32_t sample_rate);
+/* zero-copy variant: d_pcm is a device pointer that stays valid until the next
+ * upload/bind/destroy; it must be 16-byte aligned and followed by >= 16 readable bytes. */
+int pce_bind_pcm_s16_device(pce_ctx *ctx, const void *d_pcm, const int64_t *offsets, int32_t n_clips, int32_t sample_rate);
+int pce_num_clips(const pce_ctx *ctx);
+
+/* ---- R3 / R7: short-time energy, peak, silence gate --------------------
+ * Replaces _calculate_loudness (Code/Pipeline/compute_loudness_adjustments.py:8-25),
+ * _check_audio_content (Code/Aligners/use_whisper_timestamped.py:197-229 and its
+ * inline copy :581-599) and the np.abs(samples).max() of get_lufs
+ * (Code/audioPipeline.py:349).  All fields are exact integers; the few
+ * floating-point finishing operations (sqrt/log10) are host logic. */
+typedef struct pce_energy {
+    int64_t n;              /* samples in the slice, virtual zeros included           */
+    int64_t sum_sq;         /* sum of x*x (true integer squares)                      */
+    int64_t sum_sq_wrap16;  /* sum of (int16)(x*x): numpy int16 ** 2 wraparound (R3)  */
+    int64_t n_loud;         /* count of (int16)abs(x) > loud_threshold  (R7; abs(-32768) wraps to -32768) */
+    int32_t peak_abs;       /* max |x| as a true integer (0..32768)                   */
+    int32_t reserved;
+} pce_energy;
+int pce_energy_run(pce_ctx *ctx, const pce_slice *slices, int32_t n_slices, int32_t loud_threshold);
+int pce_energy_fetch(pce_ctx *ctx, pce_energy *out /* n_slices */);
+
+/* ---- R4: BS.1770 integrated loudness -----------------------------------
+ * Replaces pyloudnorm.Meter(rate).integrated_loudness(samples / peak) as called
+ * by get_lufs (Code/audioPipeline.py:338-358): peak normalisation, K-weighting
+ * biquads designed for the batch's sample rate, 400 ms / 75 % blocks, -70 LKFS and
+ * -10 LU gates.  status[i] = PCE_SLICE_TOO_SHORT where pyloudnorm raises
+ * ValueError (n < 0.4 * rate); the whole-file fallback is the caller's. */
+int pce_lufs_run(pce_ctx *ctx, const pce_slice *slices, int32_t n_slices);
+int pce_lufs_fetch(pce_ctx *ctx, double *lufs /* n_slices */, int32_t *status /* n_slices */);
+
+/* ---- R1 / R2: Praat autocorrelation pitch ------------------------------
+ * Replaces parselmouth Sound.to_pitch(pitch_floor, pitch_ceiling) followed by
+ * selected_array["frequency"] and the voiced median (get_median_pitch,
+ * Code/audioPipeline.py:326-335) or the voiced geometric mean
+ * (calculate_pitch_segment, Code/Pipeline/compute_pitch_adjustments.py:167-208). */
+typedef struct pce_pitch_params {
+    double  time_step;            /* <= 0: 0.75 / pitch_floor                    */
+    double  pitch_floor;
+    double  periods_per_window;   /* 3.0                                         */
+    int32_t max_candidates;       /* 15                                          */
+    int32_t reserved;
+    double  silence_threshold;    /* 0.03 */
+    double  voicing_threshold;    /* 0.45 */
+    double  octave_cost;          /* 0.01 */
+    double  octave_jump_cost;     /* 0.35 */
+    double  voiced_unvoiced_cost; /* 0.14 */
+    double  pitch_ceiling;
+} pce_pitch_params;
+
+typedef struct pce_pitch_summary {
+    int64_t n_frames;     /* 0 when status != PCE_SLICE_OK                             */
+    int64_t n_voiced;     /* frames with f0 > 0                                        */
+    double  median_f0;    /* np.median of voiced f0, 0.0 when none                     */
+    double  mean_log_f0;  /* mean of ln(f0) over voiced frames (exp -> geometric mean) */
+    double  t1;           /* centre time of the first frame                            */
+    int32_t status;       /* pce_slice_status                                          */
+    int32_t reserved;
+} pce_pitch_summary;
+
+/* Host-only sizing: frame_offsets[n_slices+1] (prefix sum of frame counts). */
+int pce_pitch_plan(pce_ctx *ctx, const pce_pitch_params *p, const pce_slice *slices, int32_t n_slices,
+                   int64_t *frame_offsets, int32_t *status);
+int pce_pitch_run(pce_ctx *ctx, const pce_pitch_params *p, const pce_slice *slices, int32_t n_slices);
+/* f0 / strength: ragged [frame_offsets[n_slices]], either may be NULL. */
+int pce_pitch_fetch(pce_ctx *ctx, double *f0, double *strength, pce_pitch_summary *summary /* n_slices */);
+
+/* ---- R10: STFT magnitude in dB -----------------------------------------
+ * Replaces librosa.amplitude_to_db(np.abs(librosa.stft(y, n_fft, hop_length)),
+ * ref=np.max) (Code/visualisation/app.py:69-72, acoustic_analysis.py:76-90):
+ * periodic Hann, centred frames with zero padding, float32, amin 1e-5, top_db 80.
+ * One [n_fft/2+1, 1+n/hop] row-major float32 matrix per uploaded clip. */
+int pce_stft_db_run(pce_ctx *ctx, int32_t n_fft, int32_t hop);
+int pce_stft_db_shape(pce_ctx *ctx, int32_t clip, int32_t *n_bins, int32_t *n_frames);
+int pce_stft_db_fetch(pce_ctx *ctx, int32_t clip, float *out);
+/* device pointer + byte size of the resident result (all clips, concatenated) */
+int pce_stft_db_device(pce_ctx *ctx, const void **d_ptr, int64_t *bytes);
+
+/* ---- measurement -------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the
+ * context's stream; pce_profile_get returns the accumulated device time. */
+enum pce_kernel_id {
+    PCE_K_ENERGY = 0,
+    PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
+    PCE_K_PITCH_PEAK, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN,
+    PCE_K_STFT_MAX, PCE_K_STFT_DB,
+    PCE_K_COUNT
+};
+int pce_profile_enable(pce_ctx *ctx, int on);
+int pce_profile_reset(pce_ctx *ctx);
+int pce_profile_get(pce_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+const char *pce_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCE_H */

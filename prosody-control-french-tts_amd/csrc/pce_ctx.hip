@@ -1,0 +1,191 @@
+// pce_ctx.hip -- context, batch residency, profiling brackets of libpce.so.
+#include "pce_internal.h"
+#include <cstdarg>
+
+int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+KernelTimer::KernelTimer(pce_ctx *ctx, int kid) : c(ctx), id(kid)
+{
+    if (!c->prof) return;
+    auto take = [&]() -> hipEvent_t {
+        if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    };
+    a = take(); b = take();
+    if (a) (void)hipEventRecord(a, c->stream);
+}
+KernelTimer::~KernelTimer()
+{
+    if (!c->prof || !a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({id, a, b});
+}
+void pce_profile_collect(pce_ctx *ctx)
+{
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof_ms[p.id] += ms;
+            ctx->prof_n[p.id] += 1;
+        }
+        ctx->ev_pool.push_back(p.a);
+        ctx->ev_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" {
+
+int pce_api_version(void) { return PCE_API_VERSION; }
+
+pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
+{
+    auto fail = [&](const char *what, hipError_t e) -> pce_ctx * {
+        if (err && errlen) snprintf(err, errlen, "%s: %s", what, hipGetErrorString(e));
+        return nullptr;
+    };
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (err && errlen) snprintf(err, errlen, "no HIP device available (libpce has no CPU fallback): %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        if (err && errlen) snprintf(err, errlen, "device %d out of range (0..%d)", device, n - 1);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+    pce_ctx *c = new (std::nothrow) pce_ctx();
+    if (!c) { if (err && errlen) snprintf(err, errlen, "out of host memory"); return nullptr; }
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
+        c->own_stream = true;
+    }
+    return c;
+}
+
+void pce_destroy(pce_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    pce_profile_collect(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    DevBuf *bufs[] = {&c->pcm_own, &c->d_clip_off, &c->en_work, &c->en_out,
+                      &c->lu_meta, &c->lu_chunks, &c->lu_blocks, &c->lu_pow, &c->lu_state_end, &c->lu_state_init,
+                      &c->lu_energy, &c->lu_zbuf, &c->lu_out, &c->lu_en_work, &c->lu_en_acc,
+                      &c->pi_meta, &c->pi_window, &c->pi_windowR, &c->pi_work, &c->pi_cand, &c->pi_gpeak,
+                      &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc,
+                      &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work};
+    for (auto b : bufs) b->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pce_last_error(const pce_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int pce_sync(pce_ctx *c)
+{
+    if (!c) return PCE_E_INVALID;
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    return PCE_OK;
+}
+
+int pce_device_info(pce_ctx *c, char *name, size_t namelen, int32_t *cus, int64_t *hbm)
+{
+    if (!c) return PCE_E_INVALID;
+    hipDeviceProp_t prop;
+    PCE_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    if (name && namelen) snprintf(name, namelen, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+    return PCE_OK;
+}
+
+static int set_offsets(pce_ctx *c, const int64_t *offsets, int32_t n_clips, int32_t rate)
+{
+    if (!offsets || n_clips <= 0 || rate <= 0) return pce_fail(c, PCE_E_INVALID, "bad batch description");
+    if (offsets[0] != 0) return pce_fail(c, PCE_E_INVALID, "offsets[0] must be 0");
+    for (int32_t i = 0; i < n_clips; i++)
+        if (offsets[i + 1] < offsets[i]) return pce_fail(c, PCE_E_INVALID, "offsets must be non-decreasing");
+    c->clip_off.assign(offsets, offsets + n_clips + 1);
+    c->n_clips = n_clips; c->rate = rate;
+    PCE_HIP(c, c->d_clip_off.reserve(sizeof(int64_t) * (size_t)(n_clips + 1)));
+    PCE_HIP(c, hipMemcpyAsync(c->d_clip_off.p, offsets, sizeof(int64_t) * (size_t)(n_clips + 1), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    c->en_n = c->lu_n = c->pi_n = -1; c->st_nfft = 0; c->st_ran = false;
+    c->en_cache.drop(); c->lu_cache.drop(); c->pi_cache.drop();
+    return PCE_OK;
+}
+
+int pce_upload_pcm_s16(pce_ctx *c, const int16_t *pcm, const int64_t *offsets, int32_t n_clips, int32_t rate)
+{
+    if (!c || !pcm) return PCE_E_INVALID;
+    PCE_HIP(c, hipSetDevice(c->device));
+    int st = set_offsets(c, offsets, n_clips, rate);
+    if (st) return st;
+    size_t total = (size_t)offsets[n_clips];
+    // 64 bytes of zero slack so that 16-byte vector loads may run past the last sample
+    PCE_HIP(c, c->pcm_own.reserve(total * 2 + 64));
+    PCE_HIP(c, hipMemsetAsync((char *)c->pcm_own.p + total * 2, 0, 64, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(c->pcm_own.p, pcm, total * 2, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    c->d_pcm = c->pcm_own.as<const int16_t>();
+    return PCE_OK;
+}
+
+int pce_bind_pcm_s16_device(pce_ctx *c, const void *d_pcm, const int64_t *offsets, int32_t n_clips, int32_t rate)
+{
+    if (!c || !d_pcm) return PCE_E_INVALID;
+    if (((uintptr_t)d_pcm) & 15) return pce_fail(c, PCE_E_INVALID, "device PCM pointer must be 16-byte aligned");
+    PCE_HIP(c, hipSetDevice(c->device));
+    int st = set_offsets(c, offsets, n_clips, rate);
+    if (st) return st;
+    c->d_pcm = (const int16_t *)d_pcm;
+    return PCE_OK;
+}
+
+int pce_num_clips(const pce_ctx *c) { return c ? c->n_clips : 0; }
+
+int pce_profile_enable(pce_ctx *c, int on) { if (!c) return PCE_E_INVALID; c->prof = on != 0; return PCE_OK; }
+int pce_profile_reset(pce_ctx *c)
+{
+    if (!c) return PCE_E_INVALID;
+    pce_profile_collect(c);
+    for (int i = 0; i < PCE_K_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return PCE_OK;
+}
+int pce_profile_get(pce_ctx *c, int id, double *ms, int64_t *n)
+{
+    if (!c || id < 0 || id >= PCE_K_COUNT) return PCE_E_INVALID;
+    pce_profile_collect(c);
+    if (ms) *ms = c->prof_ms[id];
+    if (n) *n = c->prof_n[id];
+    return PCE_OK;
+}
+const char *pce_kernel_name(int id)
+{
+    static const char *names[PCE_K_COUNT] = {
+        "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
+        "k_pitch_peak", "k_pitch_frames", "k_pitch_path", "k_pitch_median",
+        "k_stft_max", "k_stft_db"};
+    return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
+}
+
+} // extern "C"

@@ -1,0 +1,201 @@
+// pce_energy.hip -- k_energy: exact integer short-time energy / peak / gate counts per slice.
+//
+// Reference arithmetic replaced (all reference-owned, pinned by goldens G3/G4):
+//   Code/Pipeline/compute_loudness_adjustments.py:17-21  samples**2 on int16 (wraps), mean
+//   Code/Aligners/use_whisper_timestamped.py:204-210      mean(square(f32)), count(|x| > 500)
+//   Code/audioPipeline.py:349                             np.abs(samples).max()
+//
+// Roofline: HBM-bound, 2 algorithmic bytes per sample read once, O(1) bytes written.
+// Layout: int16 PCM, clips concatenated; each 256-thread block streams one chunk of up to
+// CHUNK samples with 16-byte loads (8 samples / lane / load, 4 KiB per wave-instruction
+// group), reduces in registers -> wave shuffles -> LDS -> one set of integer atomics per
+// block.  Integer accumulation makes the result independent of the reduction order.
+#include "pce_internal.h"
+
+namespace {
+
+constexpr int EN_THREADS = 256;
+constexpr int EN_ITERS = 8;
+constexpr int64_t EN_CHUNK = (int64_t)EN_THREADS * 8 * EN_ITERS;   // 16384 samples = 32 KiB
+
+struct EnWork { int64_t g0, g1; int32_t slice; int32_t pad; };
+// m_hi = max(x + 32769) and m_lo = max(32768 - x) over the real samples (0 = no sample seen):
+// zero-initialisable encodings of the slice maximum and minimum, used by the pitch path.
+struct EnAcc { unsigned long long sum_sq; long long sum_wrap; unsigned long long n_loud; long long sum; int peak; int m_hi; int m_lo; int pad; };
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_energy(const int16_t *__restrict__ pcm, const EnWork *__restrict__ work,
+                                                      int loud_thr, EnAcc *__restrict__ out)
+{
+    const EnWork w = work[blockIdx.x];
+    const int64_t a0 = w.g0 & ~(int64_t)7;
+    unsigned long long s_sq = 0; int s_wrap = 0; int n_loud = 0; int peak = 0; int s_sum = 0; int m_hi = 0, m_lo = 0;
+    for (int64_t pos = a0 + (int64_t)threadIdx.x * 8; pos < w.g1; pos += (int64_t)EN_THREADS * 8) {
+        const int4 v = *reinterpret_cast<const int4 *>(pcm + pos);
+        const int words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int lo = (int)(short)(words[k] & 0xFFFF), hi = words[k] >> 16;
+            const int64_t i0 = pos + 2 * k, i1 = i0 + 1;
+            const bool ok0 = i0 >= w.g0 && i0 < w.g1, ok1 = i1 >= w.g0 && i1 < w.g1;
+            const int x0 = ok0 ? lo : 0, x1 = ok1 ? hi : 0;
+            const unsigned int q0 = (unsigned int)(x0 * x0), q1 = (unsigned int)(x1 * x1);
+            s_sq += (unsigned long long)q0 + (unsigned long long)q1;
+            s_wrap += (int)(short)(q0 & 0xFFFFu) + (int)(short)(q1 & 0xFFFFu);
+            const int ab0 = x0 < 0 ? -x0 : x0, ab1 = x1 < 0 ? -x1 : x1;
+            peak = max(peak, max(ab0, ab1));
+            n_loud += ((int)(short)ab0 > loud_thr) + ((int)(short)ab1 > loud_thr);
+            s_sum += x0 + x1;
+            m_hi = max(m_hi, max(ok0 ? x0 + 32769 : 0, ok1 ? x1 + 32769 : 0));
+            m_lo = max(m_lo, max(ok0 ? 32768 - x0 : 0, ok1 ? 32768 - x1 : 0));
+        }
+    }
+    __shared__ unsigned long long l_sq[EN_THREADS / 64];
+    __shared__ long long l_wrap[EN_THREADS / 64];
+    __shared__ unsigned long long l_loud[EN_THREADS / 64];
+    __shared__ int l_peak[EN_THREADS / 64];
+    __shared__ long long l_sum[EN_THREADS / 64];
+    __shared__ int l_hi[EN_THREADS / 64], l_lo[EN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long r_sq = wave_sum_u64(s_sq);
+    const long long r_wrap = wave_sum_i64((long long)s_wrap);
+    const unsigned long long r_loud = wave_sum_u64((unsigned long long)n_loud);
+    const int r_peak = wave_max_i32(peak);
+    const long long r_sum = wave_sum_i64((long long)s_sum);
+    const int r_hi = wave_max_i32(m_hi), r_lo = wave_max_i32(m_lo);
+    if (lane == 0) { l_sq[wv] = r_sq; l_wrap[wv] = r_wrap; l_loud[wv] = r_loud; l_peak[wv] = r_peak; l_sum[wv] = r_sum; l_hi[wv] = r_hi; l_lo[wv] = r_lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t_sq = 0, t_loud = 0; long long t_wrap = 0, t_sum = 0; int t_peak = 0, t_hi = 0, t_lo = 0;
+        for (int i = 0; i < EN_THREADS / 64; i++) {
+            t_sq += l_sq[i]; t_wrap += l_wrap[i]; t_loud += l_loud[i]; t_peak = max(t_peak, l_peak[i]);
+            t_sum += l_sum[i]; t_hi = max(t_hi, l_hi[i]); t_lo = max(t_lo, l_lo[i]);
+        }
+        EnAcc *o = out + w.slice;
+        atomicAdd(&o->sum_sq, t_sq);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&o->sum_wrap), (unsigned long long)t_wrap);
+        atomicAdd(&o->n_loud, t_loud);
+        atomicMax(&o->peak, t_peak);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&o->sum), (unsigned long long)t_sum);
+        atomicMax(&o->m_hi, t_hi);
+        atomicMax(&o->m_lo, t_lo);
+    }
+}
+
+} // namespace
+
+// Plan (host): clamp every slice to its clip and cut it into 16-byte-aligned chunks.
+// Shared with the LUFS path, which needs per-slice peaks resident on the device.
+int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work_buf, DevBuf &out_buf, int64_t *n_work)
+{
+    std::vector<EnWork> work;
+    for (int32_t i = 0; i < n; i++) {
+        const pce_slice &s = slices[i];
+        if (s.clip < 0 || s.clip >= c->n_clips) return pce_fail(c, PCE_E_INVALID, "slice %d: clip %d out of range", i, s.clip);
+        if (s.end < s.begin) return pce_fail(c, PCE_E_INVALID, "slice %d: end < begin", i);
+        const int64_t len = c->clip_off[s.clip + 1] - c->clip_off[s.clip];
+        int64_t b = s.begin < 0 ? 0 : s.begin, e = s.end > len ? len : s.end;
+        if (e <= b) continue;
+        const int64_t g0 = c->clip_off[s.clip] + b, g1 = c->clip_off[s.clip] + e;
+        for (int64_t p = g0; p < g1;) {
+            int64_t q = ((p / EN_CHUNK) + 1) * EN_CHUNK;
+            if (q > g1) q = g1;
+            work.push_back({p, q, i, 0});
+            p = q;
+        }
+    }
+    PCE_HIP(c, out_buf.reserve(sizeof(EnAcc) * (size_t)(n > 0 ? n : 1)));
+    PCE_HIP(c, work_buf.reserve(sizeof(EnWork) * (work.size() + 1)));
+    if (!work.empty())
+        PCE_HIP(c, hipMemcpyAsync(work_buf.p, work.data(), sizeof(EnWork) * work.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));   // `work` is pageable and dies at return
+    *n_work = (int64_t)work.size();
+    return PCE_OK;
+}
+
+// Launch (async): zero the accumulators, stream the chunks.
+int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf)
+{
+    PCE_HIP(c, hipMemsetAsync(out_buf.p, 0, sizeof(EnAcc) * (size_t)(n > 0 ? n : 1), c->stream));
+    if (n_work > 0) {
+        KernelTimer t(c, PCE_K_ENERGY);
+        hipLaunchKernelGGL(k_energy, dim3((unsigned)n_work), dim3(EN_THREADS), 0, c->stream,
+                           c->d_pcm, work_buf.as<EnWork>(), (int)loud_thr, out_buf.as<EnAcc>());
+        PCE_HIP(c, hipGetLastError());
+    }
+    return PCE_OK;
+}
+
+// Device-side views of the accumulators for other translation units.
+void pce_energy_range_ptrs(const DevBuf &out_buf, size_t *stride_bytes, const long long **sum, const int **m_hi, const int **m_lo)
+{
+    *stride_bytes = sizeof(EnAcc);
+    const char *b = reinterpret_cast<const char *>(out_buf.p);
+    *sum = reinterpret_cast<const long long *>(b + offsetof(EnAcc, sum));
+    *m_hi = reinterpret_cast<const int *>(b + offsetof(EnAcc, m_hi));
+    *m_lo = reinterpret_cast<const int *>(b + offsetof(EnAcc, m_lo));
+}
+
+const int *pce_energy_peak_ptr(const DevBuf &out_buf, size_t *stride_bytes)
+{
+    *stride_bytes = sizeof(EnAcc);
+    return reinterpret_cast<const int *>(reinterpret_cast<const char *>(out_buf.p) + offsetof(EnAcc, peak));
+}
+
+extern "C" {
+
+int pce_energy_run(pce_ctx *c, const pce_slice *slices, int32_t n, int32_t loud_thr)
+{
+    if (!c || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
+    if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
+    PCE_HIP(c, hipSetDevice(c->device));
+    if (!c->en_cache.same(slices, n)) {
+        c->en_n = -1;
+        int st = pce_energy_plan(c, slices, n, c->en_work, c->en_out, &c->en_n_work);
+        if (st) return st;
+        c->en_cache.store(slices, n);
+    }
+    int st = pce_energy_launch(c, n, loud_thr, c->en_n_work, c->en_work, c->en_out);
+    if (st) return st;
+    c->en_n = n;
+    return PCE_OK;
+}
+
+int pce_energy_fetch(pce_ctx *c, pce_energy *out)
+{
+    if (!c || !out) return PCE_E_INVALID;
+    if (c->en_n < 0) return pce_fail(c, PCE_E_STATE, "pce_energy_fetch before pce_energy_run");
+    PCE_HIP(c, hipSetDevice(c->device));
+    std::vector<EnAcc> acc((size_t)(c->en_n > 0 ? c->en_n : 1));
+    if (c->en_n > 0)
+        PCE_HIP(c, hipMemcpyAsync(acc.data(), c->en_out.p, sizeof(EnAcc) * (size_t)c->en_n, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    for (int32_t i = 0; i < c->en_n; i++) {
+        const pce_slice &s = c->en_cache.v[(size_t)i];
+        out[i].n = s.end - s.begin;
+        out[i].sum_sq = (int64_t)acc[(size_t)i].sum_sq;
+        out[i].sum_sq_wrap16 = (int64_t)acc[(size_t)i].sum_wrap;
+        out[i].n_loud = (int64_t)acc[(size_t)i].n_loud;
+        out[i].peak_abs = acc[(size_t)i].peak;
+        out[i].reserved = 0;
+    }
+    return PCE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,124 @@
+// pce_internal.h -- shared between the translation units of libpce.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "pce.h"
+
+// Growable device buffer owned by the context.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Last slice list an op was planned for: a repeated *_run with the same slices
+// (the steady state of a batch pipeline, and of bench.py) skips the host plan.
+struct SliceCache {
+    std::vector<pce_slice> v;
+    bool valid = false;
+    bool same(const pce_slice *s, int32_t n) const {
+        return valid && (size_t)n == v.size() && (n == 0 || memcmp(v.data(), s, sizeof(pce_slice) * (size_t)n) == 0);
+    }
+    void store(const pce_slice *s, int32_t n) { v.assign(s, s + n); valid = true; }
+    void drop() { valid = false; v.clear(); }
+};
+
+struct pce_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int cu_count = 0;
+
+    // resident batch
+    DevBuf pcm_own;                 // used by pce_upload_pcm_s16
+    const int16_t *d_pcm = nullptr; // device pointer to the concatenated clips
+    DevBuf d_clip_off;              // int64[n_clips+1]
+    std::vector<int64_t> clip_off;  // host copy
+    int32_t n_clips = 0;
+    int32_t rate = 0;
+
+    // energy
+    DevBuf en_work, en_out;
+    SliceCache en_cache;
+    int64_t en_n_work = 0;
+    int32_t en_n = -1;
+
+    // lufs
+    DevBuf lu_meta, lu_chunks, lu_blocks, lu_pow, lu_state_end, lu_state_init, lu_energy, lu_zbuf, lu_out, lu_en_work, lu_en_acc;
+    SliceCache lu_cache;
+    int64_t lu_n_chunks = 0, lu_n_blocks = 0, lu_n_energy_work = 0;
+    double lu_coef[13] = {0};
+    int32_t lu_n = -1;
+    std::vector<int32_t> lu_host_status;
+
+    // pitch
+    DevBuf pi_meta, pi_window, pi_windowR, pi_work, pi_cand, pi_gpeak, pi_psi, pi_f0, pi_strength, pi_summary, pi_peakwork, pi_acc;
+    double pi_P[32] = {0};          // PiParams image
+    int64_t pi_n_work = 0, pi_n_energy_work = 0;
+    int pi_np2 = 1;
+    SliceCache pi_cache;
+    pce_pitch_params pi_params;
+    bool pi_params_valid = false;
+    int32_t pi_n = -1;
+    int64_t pi_total_frames = 0;
+    std::vector<int64_t> pi_frame_off;
+    std::vector<int32_t> pi_status;
+    std::vector<double> pi_t1;
+
+    // stft
+    DevBuf st_out, st_max, st_off, st_window, st_twiddle, st_work;
+    int32_t st_nfft = 0, st_hop = 0;
+    int64_t st_n_tiles = 0;
+    bool st_ran = false;
+    std::vector<int64_t> st_off_host;   // float offsets per clip (n_clips+1)
+    std::vector<int32_t> st_frames;
+
+    // profiling
+    bool prof = false;
+    double prof_ms[PCE_K_COUNT] = {0};
+    int64_t prof_n[PCE_K_COUNT] = {0};
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...);
+#define PCE_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return pce_fail((ctx), PCE_E_DEVICE, "%s: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// Kernel-launch bracket for the profiler: records events around the launch when enabled.
+struct KernelTimer {
+    pce_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(pce_ctx *ctx, int kid);
+    ~KernelTimer();
+};
+void pce_profile_collect(pce_ctx *ctx);
+
+// Host-side copy of the sizes Praat derives before its frame loop (see pce_pitch.hip).
+struct PitchPlan {
+    double dt, t1, ceiling, dt_window;
+    int64_t n_frames, nsamp_period, halfnsamp_period, nsamp_window, halfnsamp_window;
+    int64_t maximum_lag, brent_ixmax, max_candidates;
+};
+int pitch_plan_make(int64_t nx, double dx, double x1, const pce_pitch_params *p, PitchPlan *pl);
+
+static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,355 @@
+// pce_lufs.hip -- BS.1770 integrated loudness of peak-normalised slices (R4).
+//
+// Replaces, per slice, what get_lufs (Code/audioPipeline.py:338-358) delegates to
+// pyloudnorm: x/peak -> high-shelf biquad -> high-pass biquad (direct form II
+// transposed, as scipy.signal.lfilter) -> mean squares of 400 ms blocks with 75 %
+// overlap -> absolute (-70 LKFS) and relative (-10 LU) gates -> LUFS.
+//
+// The IIR recurrence is sequential in time, so a slice is cut into chunks whose
+// boundaries contain every gating-block boundary pyloudnorm computes
+// (int(T_g*(j*step)*rate), int(T_g*(j*step+1)*rate)) and which are at most LU_LMAX
+// samples long.  The filter cascade is linear, so with s the 4-element state
+//     state_end(chunk) = A^len * state_begin(chunk) + zero_state_response_end(chunk)
+// and three passes make every chunk independent:
+//   k_lufs_pass1  one thread per chunk: run the cascade from a zero state, keep the end state
+//   k_lufs_scan   one thread per slice: propagate true begin states through its chunks
+//   k_lufs_pass2  one thread per chunk: run again from the true state, sum y^2
+//   k_lufs_gate   one thread per slice: block energies = sums of whole chunks, gating, LUFS
+// All arithmetic is fp64 with contraction off.  Bound: fp64 VALU (about 70 dependent
+// flops per sample); algorithmic HBM traffic is 2 B/sample read twice (L2-resident
+// the second time).
+#include "pce_internal.h"
+#include <algorithm>
+#include <cmath>
+
+int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work_buf, DevBuf &out_buf, int64_t *n_work);
+int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf);
+const int *pce_energy_peak_ptr(const DevBuf &out_buf, size_t *stride_bytes);
+
+namespace {
+
+constexpr int LU_LMAX = 256;
+
+struct LuChunk { int64_t rel; int32_t len; int32_t slice; };
+struct LuSlice {
+    int64_t begin, clip_len, clip_off;     // slice start in clip coordinates, clip extent
+    int32_t first_chunk, n_chunks;
+    int32_t first_block, n_blocks;
+    int32_t status, pad;
+};
+struct LuBlock { int32_t c0, c1; };          // chunk range [c0, c1) of one gating block (indices local to the slice)
+struct LuCoef { double b[3], a[3], c[3], d[3]; double inv_norm; };   // stage 1 (b,a), stage 2 (c,d), 1/(T_g*rate)
+
+__device__ __forceinline__ double lu_sample(const int16_t *__restrict__ pcm, const LuSlice &s, int64_t rel)
+{
+    const int64_t cc = s.begin + rel;
+    return (cc >= 0 && cc < s.clip_len) ? (double)pcm[s.clip_off + cc] : 0.0;
+}
+
+template <bool SUM>
+__device__ __forceinline__ double lu_run(const int16_t *__restrict__ pcm, const LuSlice &s, const LuChunk &ch, const LuCoef &k,
+                                         double peak, double st[4])
+{
+    double z0 = st[0], z1 = st[1], w0 = st[2], w1 = st[3], acc = 0.0;
+    for (int i = 0; i < ch.len; i++) {
+        const double x = lu_sample(pcm, s, ch.rel + i) / peak;
+        const double y = k.b[0] * x + z0;
+        z0 = k.b[1] * x - k.a[1] * y + z1;
+        z1 = k.b[2] * x - k.a[2] * y;
+        const double v = k.c[0] * y + w0;
+        w0 = k.c[1] * y - k.d[1] * v + w1;
+        w1 = k.c[2] * y - k.d[2] * v;
+        if (SUM) acc += v * v;
+    }
+    st[0] = z0; st[1] = z1; st[2] = w0; st[3] = w1;
+    return acc;
+}
+
+__device__ __forceinline__ double lu_peak(const int *peaks, size_t stride, int slice)
+{
+    const int p = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(peaks) + stride * (size_t)slice);
+    return p == 0 ? 1.0 : (double)p;       // `np.abs(samples).max() or 1.0`
+}
+
+__global__ void k_lufs_pass1(const int16_t *__restrict__ pcm, const LuSlice *__restrict__ slices, const LuChunk *__restrict__ chunks,
+                             int n_chunks, LuCoef k, const int *peaks, size_t pstride, double *__restrict__ state_end)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks) return;
+    const LuChunk ch = chunks[i];
+    const LuSlice s = slices[ch.slice];
+    double st[4] = {0.0, 0.0, 0.0, 0.0};
+    lu_run<false>(pcm, s, ch, k, lu_peak(peaks, pstride, ch.slice), st);
+    double *o = state_end + 4 * (size_t)i;
+    o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
+}
+
+__global__ void k_lufs_scan(const LuSlice *__restrict__ slices, const LuChunk *__restrict__ chunks, int n_slices,
+                            const double *__restrict__ apow /* [LU_LMAX+1][16] */, const double *__restrict__ state_end,
+                            double *__restrict__ state_init)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slices) return;
+    const LuSlice s = slices[i];
+    double st[4] = {0.0, 0.0, 0.0, 0.0};
+    double m[16]; int cur_len = -1;
+    for (int c = 0; c < s.n_chunks; c++) {
+        const size_t ci = (size_t)(s.first_chunk + c);
+        double *o = state_init + 4 * ci;
+        o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
+        const int len = chunks[ci].len;
+        if (len != cur_len) {
+            for (int q = 0; q < 16; q++) m[q] = apow[(size_t)len * 16 + q];
+            cur_len = len;
+        }
+        const double *e = state_end + 4 * ci;
+        double nx[4];
+        for (int r = 0; r < 4; r++)
+            nx[r] = (((m[4 * r] * st[0] + m[4 * r + 1] * st[1]) + m[4 * r + 2] * st[2]) + m[4 * r + 3] * st[3]) + e[r];
+        st[0] = nx[0]; st[1] = nx[1]; st[2] = nx[2]; st[3] = nx[3];
+    }
+}
+
+__global__ void k_lufs_pass2(const int16_t *__restrict__ pcm, const LuSlice *__restrict__ slices, const LuChunk *__restrict__ chunks,
+                             int n_chunks, LuCoef k, const int *peaks, size_t pstride, const double *__restrict__ state_init,
+                             double *__restrict__ energy)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks) return;
+    const LuChunk ch = chunks[i];
+    const LuSlice s = slices[ch.slice];
+    const double *in = state_init + 4 * (size_t)i;
+    double st[4] = {in[0], in[1], in[2], in[3]};
+    energy[i] = lu_run<true>(pcm, s, ch, k, lu_peak(peaks, pstride, ch.slice), st);
+}
+
+__global__ void k_lufs_gate(const LuSlice *__restrict__ slices, const LuBlock *__restrict__ blocks, int n_slices, LuCoef k,
+                            const double *__restrict__ energy, double *__restrict__ zbuf, double *__restrict__ lufs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slices) return;
+    const LuSlice s = slices[i];
+    if (s.status != PCE_SLICE_OK) { lufs[i] = nan(""); return; }
+    const double *en = energy + s.first_chunk;
+    double *z = zbuf + s.first_block;
+    const double gamma_a = -70.0;
+    double sum = 0.0; int cnt = 0;
+    for (int j = 0; j < s.n_blocks; j++) {
+        const LuBlock b = blocks[s.first_block + j];
+        double e = 0.0;
+        for (int c = b.c0; c < b.c1; c++) e += en[c];
+        const double zj = k.inv_norm * e;
+        z[j] = zj;
+        const double lj = -0.691 + 10.0 * log10(zj);
+        if (lj >= gamma_a) { sum += zj; cnt++; }
+    }
+    const double zavg1 = cnt ? sum / (double)cnt : nan("");
+    const double gamma_r = -0.691 + 10.0 * log10(zavg1) - 10.0;
+    sum = 0.0; cnt = 0;
+    for (int j = 0; j < s.n_blocks; j++) {
+        const double zj = z[j];
+        const double lj = -0.691 + 10.0 * log10(zj);
+        if (lj > gamma_r && lj > gamma_a) { sum += zj; cnt++; }
+    }
+    const double zavg2 = cnt ? sum / (double)cnt : 0.0;
+    lufs[i] = -0.691 + 10.0 * log10(zavg2);
+}
+
+// pyloudnorm.IIRfilter.generate_coefficients for the two K-weighting stages
+void kweight_design(double rate, LuCoef &k)
+{
+    const double PI = 3.14159265358979323846;
+    {
+        const double G = 4.0, Q = 1.0 / std::sqrt(2.0), fc = 1500.0;
+        const double A = std::pow(10.0, G / 40.0), w0 = 2.0 * PI * (fc / rate), alpha = std::sin(w0) / (2.0 * Q);
+        const double b0 = A * ((A + 1) + (A - 1) * std::cos(w0) + 2 * std::sqrt(A) * alpha);
+        const double b1 = -2 * A * ((A - 1) + (A + 1) * std::cos(w0));
+        const double b2 = A * ((A + 1) + (A - 1) * std::cos(w0) - 2 * std::sqrt(A) * alpha);
+        const double a0 = (A + 1) - (A - 1) * std::cos(w0) + 2 * std::sqrt(A) * alpha;
+        const double a1 = 2 * ((A - 1) - (A + 1) * std::cos(w0));
+        const double a2 = (A + 1) - (A - 1) * std::cos(w0) - 2 * std::sqrt(A) * alpha;
+        k.b[0] = b0 / a0; k.b[1] = b1 / a0; k.b[2] = b2 / a0;
+        k.a[0] = a0 / a0; k.a[1] = a1 / a0; k.a[2] = a2 / a0;
+    }
+    {
+        const double Q = 0.5, fc = 38.0;
+        const double w0 = 2.0 * PI * (fc / rate), alpha = std::sin(w0) / (2.0 * Q);
+        const double b0 = (1 + std::cos(w0)) / 2, b1 = -(1 + std::cos(w0)), b2 = (1 + std::cos(w0)) / 2;
+        const double a0 = 1 + alpha, a1 = -2 * std::cos(w0), a2 = 1 - alpha;
+        k.c[0] = b0 / a0; k.c[1] = b1 / a0; k.c[2] = b2 / a0;
+        k.d[0] = a0 / a0; k.d[1] = a1 / a0; k.d[2] = a2 / a0;
+    }
+    k.inv_norm = 1.0 / (0.400 * rate);
+}
+
+// state-transition matrix of the cascade with zero input, and its powers 0..LU_LMAX
+void transition_powers(const LuCoef &k, std::vector<double> &pw)
+{
+    const double A[16] = {
+        -k.a[1], 1.0, 0.0, 0.0,
+        -k.a[2], 0.0, 0.0, 0.0,
+        k.c[1] - k.d[1] * k.c[0], 0.0, -k.d[1], 1.0,
+        k.c[2] - k.d[2] * k.c[0], 0.0, -k.d[2], 0.0};
+    pw.assign((size_t)(LU_LMAX + 1) * 16, 0.0);
+    for (int i = 0; i < 4; i++) pw[(size_t)i * 4 + i] = 1.0;
+    for (int L = 1; L <= LU_LMAX; L++) {
+        const double *prev = &pw[(size_t)(L - 1) * 16];
+        double *cur = &pw[(size_t)L * 16];
+        for (int r = 0; r < 4; r++)
+            for (int q = 0; q < 4; q++) {
+                double s = 0.0;
+                for (int t = 0; t < 4; t++) s += A[r * 4 + t] * prev[t * 4 + q];
+                cur[r * 4 + q] = s;
+            }
+    }
+}
+
+} // namespace
+
+static int lufs_plan(pce_ctx *c, const pce_slice *slices, int32_t n)
+{
+    std::vector<LuSlice> hs((size_t)(n > 0 ? n : 1));
+    std::vector<LuChunk> chunks;
+    std::vector<LuBlock> blocks;
+    const double rate = (double)c->rate;
+    const double T_g = 0.400, step = 1.0 - 0.75;
+    c->lu_host_status.assign((size_t)n, PCE_SLICE_OK);
+    std::vector<int64_t> pts;
+    for (int32_t i = 0; i < n; i++) {
+        const pce_slice &s = slices[i];
+        if (s.clip < 0 || s.clip >= c->n_clips) return pce_fail(c, PCE_E_INVALID, "slice %d: clip %d out of range", i, s.clip);
+        if (s.end < s.begin) return pce_fail(c, PCE_E_INVALID, "slice %d: end < begin", i);
+        LuSlice &h = hs[(size_t)i];
+        h.begin = s.begin; h.clip_off = c->clip_off[s.clip]; h.clip_len = c->clip_off[s.clip + 1] - c->clip_off[s.clip];
+        h.first_chunk = (int32_t)chunks.size(); h.n_chunks = 0;
+        h.first_block = (int32_t)blocks.size(); h.n_blocks = 0;
+        h.status = PCE_SLICE_OK; h.pad = 0;
+        const int64_t ns = s.end - s.begin;
+        if (ns == 0) { h.status = PCE_SLICE_EMPTY; c->lu_host_status[(size_t)i] = h.status; continue; }
+        if ((double)ns < T_g * rate) { h.status = PCE_SLICE_TOO_SHORT; c->lu_host_status[(size_t)i] = h.status; continue; }
+        // pyloudnorm: T = numSamples / rate; numBlocks = int(np.round((T - T_g) / (T_g * step)) + 1)
+        const double T = (double)ns / rate;
+        const int64_t nb = (int64_t)std::nearbyint((T - T_g) / (T_g * step)) + 1;
+        pts.clear(); pts.push_back(0);
+        std::vector<int64_t> lo((size_t)(nb > 0 ? nb : 0)), up((size_t)(nb > 0 ? nb : 0));
+        for (int64_t j = 0; j < nb; j++) {
+            int64_t l = (int64_t)(T_g * ((double)j * step) * rate);
+            int64_t u = (int64_t)(T_g * ((double)j * step + 1.0) * rate);
+            if (l > ns) l = ns;
+            if (u > ns) u = ns;
+            if (u < l) u = l;
+            lo[(size_t)j] = l; up[(size_t)j] = u;
+            pts.push_back(l); pts.push_back(u);
+        }
+        std::sort(pts.begin(), pts.end());
+        pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+        // chunks between consecutive points, each at most LU_LMAX long; remember the chunk index of every point
+        std::vector<int32_t> chunk_at(pts.size(), 0);
+        for (size_t p = 0; p + 1 < pts.size(); p++) {
+            chunk_at[p] = (int32_t)chunks.size() - h.first_chunk;
+            for (int64_t a = pts[p]; a < pts[p + 1]; a += LU_LMAX) {
+                const int64_t len = std::min<int64_t>(LU_LMAX, pts[p + 1] - a);
+                chunks.push_back({a, (int32_t)len, i});
+            }
+        }
+        chunk_at[pts.size() - 1] = (int32_t)chunks.size() - h.first_chunk;
+        h.n_chunks = (int32_t)chunks.size() - h.first_chunk;
+        for (int64_t j = 0; j < nb; j++) {
+            const size_t pl = (size_t)(std::lower_bound(pts.begin(), pts.end(), lo[(size_t)j]) - pts.begin());
+            const size_t pu = (size_t)(std::lower_bound(pts.begin(), pts.end(), up[(size_t)j]) - pts.begin());
+            blocks.push_back({chunk_at[pl], chunk_at[pu]});
+        }
+        h.n_blocks = (int32_t)nb;
+    }
+    if (chunks.size() > (size_t)INT32_MAX) return pce_fail(c, PCE_E_LIMIT, "too many LUFS chunks");
+    c->lu_n_chunks = (int64_t)chunks.size();
+    c->lu_n_blocks = (int64_t)blocks.size();
+    LuCoef k; kweight_design(rate, k);
+    std::vector<double> pw; transition_powers(k, pw);
+    static_assert(sizeof(LuCoef) == sizeof(double) * 13, "LuCoef layout");
+    memcpy(c->lu_coef, &k, sizeof k);
+
+    PCE_HIP(c, c->lu_meta.reserve(sizeof(LuSlice) * hs.size()));
+    PCE_HIP(c, c->lu_chunks.reserve(sizeof(LuChunk) * (chunks.size() + 1)));
+    PCE_HIP(c, c->lu_blocks.reserve(sizeof(LuBlock) * (blocks.size() + 1)));
+    PCE_HIP(c, c->lu_pow.reserve(sizeof(double) * pw.size()));
+    PCE_HIP(c, c->lu_state_end.reserve(sizeof(double) * 4 * (chunks.size() + 1)));
+    PCE_HIP(c, c->lu_state_init.reserve(sizeof(double) * 4 * (chunks.size() + 1)));
+    PCE_HIP(c, c->lu_energy.reserve(sizeof(double) * (chunks.size() + 1)));
+    PCE_HIP(c, c->lu_zbuf.reserve(sizeof(double) * (blocks.size() + 1)));   // per-block z scratch
+    PCE_HIP(c, c->lu_out.reserve(sizeof(double) * hs.size()));
+    PCE_HIP(c, hipMemcpyAsync(c->lu_meta.p, hs.data(), sizeof(LuSlice) * hs.size(), hipMemcpyHostToDevice, c->stream));
+    if (!chunks.empty())
+        PCE_HIP(c, hipMemcpyAsync(c->lu_chunks.p, chunks.data(), sizeof(LuChunk) * chunks.size(), hipMemcpyHostToDevice, c->stream));
+    if (!blocks.empty())
+        PCE_HIP(c, hipMemcpyAsync(c->lu_blocks.p, blocks.data(), sizeof(LuBlock) * blocks.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(c->lu_pow.p, pw.data(), sizeof(double) * pw.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    // peaks of the same slices
+    return pce_energy_plan(c, slices, n, c->lu_en_work, c->lu_en_acc, &c->lu_n_energy_work);
+}
+
+extern "C" {
+
+int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
+{
+    if (!c || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
+    if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
+    PCE_HIP(c, hipSetDevice(c->device));
+    if (!c->lu_cache.same(slices, n)) {
+        c->lu_n = -1;
+        int st = lufs_plan(c, slices, n);
+        if (st) return st;
+        c->lu_cache.store(slices, n);
+    }
+    int st = pce_energy_launch(c, n, 500, c->lu_n_energy_work, c->lu_en_work, c->lu_en_acc);
+    if (st) return st;
+    LuCoef k; memcpy(&k, c->lu_coef, sizeof k);
+    size_t pstride = 0;
+    const int *peaks = pce_energy_peak_ptr(c->lu_en_acc, &pstride);
+    const int nch = (int)c->lu_n_chunks;
+    if (nch > 0) {
+        {
+            KernelTimer t(c, PCE_K_LUFS_PASS1);
+            hipLaunchKernelGGL(k_lufs_pass1, dim3((unsigned)div_up(nch, 64)), dim3(64), 0, c->stream, c->d_pcm,
+                               c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), nch, k, peaks, pstride,
+                               c->lu_state_end.as<double>());
+        }
+        {
+            KernelTimer t(c, PCE_K_LUFS_SCAN);
+            hipLaunchKernelGGL(k_lufs_scan, dim3((unsigned)div_up(n, 64)), dim3(64), 0, c->stream,
+                               c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), (int)n, c->lu_pow.as<double>(),
+                               c->lu_state_end.as<double>(), c->lu_state_init.as<double>());
+        }
+        {
+            KernelTimer t(c, PCE_K_LUFS_PASS2);
+            hipLaunchKernelGGL(k_lufs_pass2, dim3((unsigned)div_up(nch, 64)), dim3(64), 0, c->stream, c->d_pcm,
+                               c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), nch, k, peaks, pstride,
+                               c->lu_state_init.as<double>(), c->lu_energy.as<double>());
+        }
+    }
+    if (n > 0) {
+        KernelTimer t(c, PCE_K_LUFS_GATE);
+        hipLaunchKernelGGL(k_lufs_gate, dim3((unsigned)div_up(n, 64)), dim3(64), 0, c->stream,
+                           c->lu_meta.as<LuSlice>(), c->lu_blocks.as<LuBlock>(), (int)n, k, c->lu_energy.as<double>(),
+                           c->lu_zbuf.as<double>(), c->lu_out.as<double>());
+    }
+    PCE_HIP(c, hipGetLastError());
+    c->lu_n = n;
+    return PCE_OK;
+}
+
+int pce_lufs_fetch(pce_ctx *c, double *lufs, int32_t *status)
+{
+    if (!c || !lufs) return PCE_E_INVALID;
+    if (c->lu_n < 0) return pce_fail(c, PCE_E_STATE, "pce_lufs_fetch before pce_lufs_run");
+    PCE_HIP(c, hipSetDevice(c->device));
+    if (c->lu_n > 0)
+        PCE_HIP(c, hipMemcpyAsync(lufs, c->lu_out.p, sizeof(double) * (size_t)c->lu_n, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    if (status) for (int32_t i = 0; i < c->lu_n; i++) status[i] = c->lu_host_status[(size_t)i];
+    return PCE_OK;
+}
+
+} // extern "C"

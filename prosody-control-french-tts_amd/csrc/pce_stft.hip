@@ -1,0 +1,326 @@
+// pce_stft.hip -- STFT magnitude in dB (R10) on gfx950.
+//
+// Replaces librosa.amplitude_to_db(np.abs(librosa.stft(y, n_fft=1024, hop_length=256)),
+// ref=np.max) (Code/visualisation/app.py:69-72): float32, periodic Hann, centred frames
+// with zero padding, amin 1e-5, top_db 80, output [513, 1 + n/256] row-major per clip.
+//
+// Execution plan (n_fft = 1024, the only STFT size the reference uses):
+//   - one WAVEFRONT per frame.  The 1024 real samples are packed as 512 complex points
+//     z[n] = x[2n] + i x[2n+1]; a 512-point Stockham FFT runs as three radix-8 passes with
+//     exactly one butterfly per lane per pass (512/8 = 64).  Pass 1 reads its operands
+//     straight from global memory (4-byte loads, 256 B per wave-instruction, int16 PCM,
+//     window applied in registers); the passes exchange data through one padded 4.6 KB LDS
+//     buffer per wave, in place (LDS executes a wave's accesses in order).
+//   - the real-FFT untangle reads Z[k] and Z[512-k] from LDS, forms |X[k]|, converts to dB
+//     and drops the value into an LDS tile [513][F+1] shared by the workgroup; the tile is
+//     written out with F contiguous floats per spectrum row (the matrix is frequency-major,
+//     so frames are the contiguous axis).
+//   - ref=np.max needs the clip maximum before any dB value can be written.  The output
+//     (1.28 MB per 10 s clip) is 4x the input, so instead of writing magnitudes and
+//     re-reading them, the FFT is simply run twice: k_stft_max reduces max|X| per clip
+//     (float bits through atomicMax), k_stft_db recomputes and writes the final dB once.
+//   - workgroup -> tile mapping is XCD-aware: each XCD gets a contiguous range of tiles, so
+//     the partial cache lines of neighbouring tiles of one clip meet in one L2.
+//
+// Roofline: k_stft_db is HBM-write bound: 513*4 B written per frame, 512 B of PCM read.
+#include "pce_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr int NFFT = 1024, MC = 512, NBINS = 513;
+constexpr int ZPAD(int p) { return p + (p >> 3); }          // LDS padding: one complex per 8
+constexpr int ZBUF = MC + MC / 8;                           // 576 complex per wave
+
+struct StTile { int32_t clip, frame0; };
+struct StClip { int64_t pcm_off, len, out_off; int32_t n_frames, pad; };
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }     // a * (-i)
+
+// forward 8-point DFT, in place: a[u] <- sum_t a[t] exp(-2 pi i t u / 8)
+__device__ __forceinline__ void dft8(float2 a[8])
+{
+    const float h = 0.70710678118654752440f;
+    float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+    float2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
+    float2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
+    float2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
+    b5 = make_float2((b5.x + b5.y) * h, (b5.y - b5.x) * h);       // * (1 - i)/sqrt2
+    b6 = mul_mi(b6);                                               // * -i
+    b7 = make_float2((b7.y - b7.x) * h, -(b7.x + b7.y) * h);      // * (-1 - i)/sqrt2
+    {   // even outputs
+        float2 d0 = cadd(b0, b2), d2 = csub(b0, b2), d1 = cadd(b1, b3), d3 = mul_mi(csub(b1, b3));
+        a[0] = cadd(d0, d1); a[4] = csub(d0, d1); a[2] = cadd(d2, d3); a[6] = csub(d2, d3);
+    }
+    {   // odd outputs
+        float2 d0 = cadd(b4, b6), d2 = csub(b4, b6), d1 = cadd(b5, b7), d3 = mul_mi(csub(b5, b7));
+        a[1] = cadd(d0, d1); a[5] = csub(d0, d1); a[3] = cadd(d2, d3); a[7] = csub(d2, d3);
+    }
+}
+
+// One frame: |X[k]|^2-ready magnitudes.  zb: this wave's LDS buffer; w512/w1024: twiddle tables in LDS.
+// Calls sink(k, magnitude) for k = 0..512 (k = lane + 64 t, plus k = 512 on lane 0).
+template <class Sink>
+__device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, const StClip &cl, int frame, int hop,
+                                           const float *__restrict__ window, float2 *zb, const float2 *w512, const float2 *w1024,
+                                           int lane, Sink sink)
+{
+    float2 a[8];
+    const int64_t s0 = (int64_t)frame * hop - NFFT / 2;            // first sample of the centred frame
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int n = lane + 64 * t;                               // complex index, samples 2n and 2n+1
+        const int64_t i0 = s0 + 2 * n;
+        float x0 = 0.f, x1 = 0.f;
+        if (i0 >= 0 && i0 + 1 < cl.len && (((cl.pcm_off + i0) & 1) == 0)) {
+            const int v = *reinterpret_cast<const int *>(pcm + cl.pcm_off + i0);   // 4-byte aligned pair
+            x0 = (float)(short)(v & 0xFFFF) * (1.0f / 32768.0f);
+            x1 = (float)(v >> 16) * (1.0f / 32768.0f);
+        } else {
+            if (i0 >= 0 && i0 < cl.len) x0 = (float)pcm[cl.pcm_off + i0] * (1.0f / 32768.0f);
+            if (i0 + 1 >= 0 && i0 + 1 < cl.len) x1 = (float)pcm[cl.pcm_off + i0 + 1] * (1.0f / 32768.0f);
+        }
+        a[t] = make_float2(x0 * window[2 * n], x1 * window[2 * n + 1]);
+    }
+    // pass 1 (Ns = 1): no twiddles
+    dft8(a);
+#pragma unroll
+    for (int u = 0; u < 8; u++) zb[ZPAD(lane * 8 + u)] = a[u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // pass 2 (Ns = 8)
+    {
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[t] = zb[ZPAD(lane + 64 * t)];
+        const int k = lane & 7;
+#pragma unroll
+        for (int t = 1; t < 8; t++) a[t] = cmul(a[t], w512[t * k * 8]);
+        dft8(a);
+        const int base = ((lane - k) << 3) + k;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; u++) zb[ZPAD(base + u * 8)] = a[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // pass 3 (Ns = 64)
+    {
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[t] = zb[ZPAD(lane + 64 * t)];
+#pragma unroll
+        for (int t = 1; t < 8; t++) a[t] = cmul(a[t], w512[t * lane]);
+        dft8(a);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; u++) zb[ZPAD(lane + u * 64)] = a[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // untangle the packed real transform: X[k] = E[k] + w^k O[k]
+#pragma unroll
+    for (int t = 0; t <= 8; t++) {
+        const int k = lane + 64 * t;
+        if (t == 8 && lane != 0) break;
+        const float2 zk = zb[ZPAD(k & (MC - 1))], zm = zb[ZPAD((MC - k) & (MC - 1))];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+        const float2 x = cadd(e, cmul(w1024[k], o));
+        sink(k, hypotf(x.x, x.y));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void load_tables(float2 *w512, float2 *w1024, const float2 *g512, const float2 *g1024, int tid, int nthreads)
+{
+    for (int i = tid; i < MC; i += nthreads) w512[i] = g512[i];
+    for (int i = tid; i < NBINS; i += nthreads) w1024[i] = g1024[i];
+}
+
+__device__ __forceinline__ int remap_xcd(int bid, int nb) { return ((nb & 7) == 0) ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
+
+template <int F, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_stft_max(const int16_t *__restrict__ pcm, const StClip *__restrict__ clips,
+                                                         const StTile *__restrict__ tiles, int n_tiles, int hop,
+                                                         const float *__restrict__ window, const float2 *__restrict__ g512,
+                                                         const float2 *__restrict__ g1024, unsigned int *__restrict__ clip_max)
+{
+    __shared__ float2 zbuf[WAVES][ZBUF];
+    __shared__ float2 w512[MC];
+    __shared__ float2 w1024[NBINS + 7];
+    __shared__ float red[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bid = remap_xcd((int)blockIdx.x, (int)gridDim.x);
+    load_tables(w512, w1024, g512, g1024, tid, 64 * WAVES);
+    __syncthreads();
+    float m = 0.f;
+    int clip = 0;
+    if (bid < n_tiles) {
+        const StTile tl = tiles[bid];
+        const StClip cl = clips[tl.clip];
+        clip = tl.clip;
+        for (int fr = wv; fr < F; fr += WAVES) {
+            const int frame = tl.frame0 + fr;
+            if (frame >= cl.n_frames) break;
+            stft_frame(pcm, cl, frame, hop, window, zbuf[wv], w512, w1024, lane, [&](int, float mag) { m = fmaxf(m, mag); });
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    if (tid == 0 && bid < n_tiles) {
+        float r = 0.f;
+        for (int i = 0; i < WAVES; i++) r = fmaxf(r, red[i]);
+        atomicMax(clip_max + clip, __float_as_uint(r));            // non-negative floats order as their bit patterns
+    }
+}
+
+template <int F, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_stft_db(const int16_t *__restrict__ pcm, const StClip *__restrict__ clips,
+                                                        const StTile *__restrict__ tiles, int n_tiles, int hop,
+                                                        const float *__restrict__ window, const float2 *__restrict__ g512,
+                                                        const float2 *__restrict__ g1024, const unsigned int *__restrict__ clip_max,
+                                                        float amin2, float top_db, float *__restrict__ out)
+{
+    __shared__ float2 zbuf[WAVES][ZBUF];
+    __shared__ float2 w512[MC];
+    __shared__ float2 w1024[NBINS + 7];
+    __shared__ float tile[NBINS][F + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bid = remap_xcd((int)blockIdx.x, (int)gridDim.x);
+    load_tables(w512, w1024, g512, g1024, tid, 64 * WAVES);
+    __syncthreads();
+    if (bid >= n_tiles) return;
+    const StTile tl = tiles[bid];
+    const StClip cl = clips[tl.clip];
+    const float ref = __uint_as_float(clip_max[tl.clip]);
+    const float ref_db = 10.0f * log10f(fmaxf(amin2, ref * ref));
+    const float floor_db = 0.0f - top_db;
+    const int nfr = min(F, cl.n_frames - tl.frame0);
+    for (int fr = wv; fr < nfr; fr += WAVES) {
+        stft_frame(pcm, cl, tl.frame0 + fr, hop, window, zbuf[wv], w512, w1024, lane, [&](int k, float mag) {
+            const float pw = mag * mag;
+            float db = 10.0f * log10f(fmaxf(amin2, pw));
+            db -= ref_db;
+            tile[k][fr] = fmaxf(db, floor_db);
+        });
+    }
+    __syncthreads();
+    float *o = out + cl.out_off + tl.frame0;
+    constexpr int ROWS_PER_IT = 64 * WAVES / F;
+    const int fr = tid % F, r0 = tid / F;
+    if (fr < nfr)
+        for (int k = r0; k < NBINS; k += ROWS_PER_IT) o[(int64_t)k * cl.n_frames + fr] = tile[k][fr];
+}
+
+} // namespace
+
+extern "C" {
+
+int pce_stft_db_run(pce_ctx *c, int32_t n_fft, int32_t hop)
+{
+    if (!c) return PCE_E_INVALID;
+    if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
+    if (n_fft != NFFT) return pce_fail(c, PCE_E_LIMIT, "n_fft %d unsupported (the engine implements the reference's n_fft=1024)", n_fft);
+    if (hop <= 0 || hop > NFFT) return pce_fail(c, PCE_E_INVALID, "bad hop %d", hop);
+    PCE_HIP(c, hipSetDevice(c->device));
+    constexpr int F = 16, WAVES = 4;
+    if (c->st_nfft != n_fft || c->st_hop != hop) {
+        const int32_t n = c->n_clips;
+        std::vector<StClip> clips((size_t)n);
+        std::vector<StTile> tiles;
+        c->st_off_host.assign((size_t)n + 1, 0);
+        c->st_frames.assign((size_t)n, 0);
+        for (int32_t i = 0; i < n; i++) {
+            const int64_t len = c->clip_off[(size_t)i + 1] - c->clip_off[(size_t)i];
+            const int64_t nf = 1 + len / hop;
+            if (nf > INT32_MAX) return pce_fail(c, PCE_E_LIMIT, "clip %d too long", i);
+            clips[(size_t)i] = {c->clip_off[(size_t)i], len, c->st_off_host[(size_t)i], (int32_t)nf, 0};
+            c->st_frames[(size_t)i] = (int32_t)nf;
+            c->st_off_host[(size_t)i + 1] = c->st_off_host[(size_t)i] + nf * NBINS;
+            for (int64_t f = 0; f < nf; f += F) tiles.push_back({i, (int32_t)f});
+        }
+        if (tiles.size() > (size_t)INT32_MAX - 8) return pce_fail(c, PCE_E_LIMIT, "too many STFT tiles");
+        c->st_n_tiles = (int64_t)tiles.size();
+        // tables: periodic Hann (scipy.signal.get_window('hann', n, fftbins=True)) and twiddles, rounded from double
+        std::vector<float> window((size_t)NFFT);
+        const double PI = 3.14159265358979323846;
+        for (int i = 0; i < NFFT; i++) window[(size_t)i] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * (double)i / (double)NFFT));
+        std::vector<float> tw((size_t)(MC + NBINS + 7) * 2, 0.f);
+        for (int i = 0; i < MC; i++) { tw[2 * (size_t)i] = (float)std::cos(2.0 * PI * i / MC); tw[2 * (size_t)i + 1] = (float)(-std::sin(2.0 * PI * i / MC)); }
+        for (int i = 0; i < NBINS; i++) {
+            tw[2 * (size_t)(MC + i)] = (float)std::cos(2.0 * PI * i / NFFT);
+            tw[2 * (size_t)(MC + i) + 1] = (float)(-std::sin(2.0 * PI * i / NFFT));
+        }
+        PCE_HIP(c, c->st_off.reserve(sizeof(StClip) * (size_t)n));
+        PCE_HIP(c, c->st_work.reserve(sizeof(StTile) * (tiles.size() + 1)));
+        PCE_HIP(c, c->st_window.reserve(sizeof(float) * window.size()));
+        PCE_HIP(c, c->st_twiddle.reserve(sizeof(float) * tw.size()));
+        PCE_HIP(c, c->st_max.reserve(sizeof(unsigned int) * (size_t)n));
+        PCE_HIP(c, c->st_out.reserve(sizeof(float) * (size_t)c->st_off_host[(size_t)n] + 64));
+        PCE_HIP(c, hipMemcpyAsync(c->st_off.p, clips.data(), sizeof(StClip) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipMemcpyAsync(c->st_work.p, tiles.data(), sizeof(StTile) * tiles.size(), hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipMemcpyAsync(c->st_window.p, window.data(), sizeof(float) * window.size(), hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipMemcpyAsync(c->st_twiddle.p, tw.data(), sizeof(float) * tw.size(), hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipStreamSynchronize(c->stream));
+        c->st_nfft = n_fft; c->st_hop = hop;
+    }
+    const int nt = (int)c->st_n_tiles;
+    const unsigned grid = (unsigned)((nt + 7) & ~7);
+    const float2 *g512 = c->st_twiddle.as<float2>();
+    const float2 *g1024 = g512 + MC;
+    PCE_HIP(c, hipMemsetAsync(c->st_max.p, 0, sizeof(unsigned int) * (size_t)c->n_clips, c->stream));
+    {
+        KernelTimer t(c, PCE_K_STFT_MAX);
+        hipLaunchKernelGGL((k_stft_max<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
+                           c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>());
+    }
+    {
+        KernelTimer t(c, PCE_K_STFT_DB);
+        hipLaunchKernelGGL((k_stft_db<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
+                           c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>(),
+                           1e-10f, 80.0f, c->st_out.as<float>());
+    }
+    PCE_HIP(c, hipGetLastError());
+    c->st_ran = true;
+    return PCE_OK;
+}
+
+int pce_stft_db_shape(pce_ctx *c, int32_t clip, int32_t *n_bins, int32_t *n_frames)
+{
+    if (!c) return PCE_E_INVALID;
+    if (!c->st_nfft) return pce_fail(c, PCE_E_STATE, "pce_stft_db_shape before pce_stft_db_run");
+    if (clip < 0 || clip >= c->n_clips) return pce_fail(c, PCE_E_INVALID, "clip out of range");
+    if (n_bins) *n_bins = NBINS;
+    if (n_frames) *n_frames = c->st_frames[(size_t)clip];
+    return PCE_OK;
+}
+
+int pce_stft_db_fetch(pce_ctx *c, int32_t clip, float *out)
+{
+    if (!c || !out) return PCE_E_INVALID;
+    if (!c->st_nfft || !c->st_ran) return pce_fail(c, PCE_E_STATE, "pce_stft_db_fetch before pce_stft_db_run");
+    if (clip < 0 || clip >= c->n_clips) return pce_fail(c, PCE_E_INVALID, "clip out of range");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int64_t off = c->st_off_host[(size_t)clip], cnt = c->st_off_host[(size_t)clip + 1] - off;
+    PCE_HIP(c, hipMemcpyAsync(out, c->st_out.as<float>() + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    return PCE_OK;
+}
+
+int pce_stft_db_device(pce_ctx *c, const void **d_ptr, int64_t *bytes)
+{
+    if (!c) return PCE_E_INVALID;
+    if (!c->st_nfft || !c->st_ran) return pce_fail(c, PCE_E_STATE, "pce_stft_db_device before pce_stft_db_run");
+    if (d_ptr) *d_ptr = c->st_out.p;
+    if (bytes) *bytes = (int64_t)sizeof(float) * c->st_off_host[(size_t)c->n_clips];
+    return PCE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,291 @@
+"""ctypes binding of ``libpce.so`` (C ABI: ``include/pce.h``).
+
+:class:`ProsodyEngine` owns one ``pce_ctx`` (one process, one GPU).  A batch of clips is
+uploaded once and stays resident in HBM; every measurement the reference takes by
+re-decoding the file (Code/audioPipeline.py:314-361) becomes a slice of that batch.
+There is no CPU path: without the built library or without a GPU, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpce.so")
+
+
+class PceError(RuntimeError):
+    pass
+
+
+def native_library_path() -> str:
+    return _LIB_PATH
+
+
+def build_native(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``libpce.so`` (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(_LIB_PATH):
+        raise PceError("build did not produce libpce.so")
+    return _LIB_PATH
+
+
+class Slice(C.Structure):
+    _fields_ = [("clip", C.c_int32), ("flags", C.c_int32), ("begin", C.c_int64), ("end", C.c_int64), ("x1", C.c_double)]
+
+
+class Energy(C.Structure):
+    _fields_ = [("n", C.c_int64), ("sum_sq", C.c_int64), ("sum_sq_wrap16", C.c_int64), ("n_loud", C.c_int64),
+                ("peak_abs", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PitchParams(C.Structure):
+    _fields_ = [("time_step", C.c_double), ("pitch_floor", C.c_double), ("periods_per_window", C.c_double),
+                ("max_candidates", C.c_int32), ("reserved", C.c_int32), ("silence_threshold", C.c_double),
+                ("voicing_threshold", C.c_double), ("octave_cost", C.c_double), ("octave_jump_cost", C.c_double),
+                ("voiced_unvoiced_cost", C.c_double), ("pitch_ceiling", C.c_double)]
+
+    @classmethod
+    def praat(cls, pitch_floor=75.0, pitch_ceiling=600.0, time_step=0.0):
+        """parselmouth ``Sound.to_pitch(time_step, pitch_floor, pitch_ceiling)`` defaults."""
+        return cls(time_step or 0.0, float(pitch_floor), 3.0, 15, 0, 0.03, 0.45, 0.01, 0.35, 0.14, float(pitch_ceiling))
+
+
+class PitchSummary(C.Structure):
+    _fields_ = [("n_frames", C.c_int64), ("n_voiced", C.c_int64), ("median_f0", C.c_double), ("mean_log_f0", C.c_double),
+                ("t1", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+SLICE_DTYPE = np.dtype([("clip", "<i4"), ("flags", "<i4"), ("begin", "<i8"), ("end", "<i8"), ("x1", "<f8")])
+ENERGY_DTYPE = np.dtype([("n", "<i8"), ("sum_sq", "<i8"), ("sum_sq_wrap16", "<i8"), ("n_loud", "<i8"),
+                         ("peak_abs", "<i4"), ("reserved", "<i4")])
+SUMMARY_DTYPE = np.dtype([("n_frames", "<i8"), ("n_voiced", "<i8"), ("median_f0", "<f8"), ("mean_log_f0", "<f8"),
+                          ("t1", "<f8"), ("status", "<i4"), ("reserved", "<i4")])
+assert SLICE_DTYPE.itemsize == C.sizeof(Slice) and ENERGY_DTYPE.itemsize == C.sizeof(Energy)
+assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
+
+SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
+
+KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
+              "k_pitch_peak", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_stft_max", "k_stft_db"]
+
+# every symbol include/pce.h declares
+EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
+           "pce_upload_pcm_s16", "pce_bind_pcm_s16_device", "pce_num_clips",
+           "pce_energy_run", "pce_energy_fetch", "pce_lufs_run", "pce_lufs_fetch",
+           "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
+           "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
+           "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
+
+
+def load_library() -> C.CDLL:
+    if not os.path.exists(_LIB_PATH):
+        raise PceError(f"{_LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                       "this engine has no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.pce_create.argtypes = [C.c_int, vp, C.c_char_p, C.c_size_t]; lib.pce_create.restype = vp
+    lib.pce_destroy.argtypes = [vp]; lib.pce_destroy.restype = None
+    lib.pce_last_error.argtypes = [vp]; lib.pce_last_error.restype = C.c_char_p
+    lib.pce_sync.argtypes = [vp]
+    lib.pce_api_version.argtypes = []
+    lib.pce_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(i64)]
+    lib.pce_upload_pcm_s16.argtypes = [vp, vp, vp, i32, i32]
+    lib.pce_bind_pcm_s16_device.argtypes = [vp, vp, vp, i32, i32]
+    lib.pce_num_clips.argtypes = [vp]
+    lib.pce_energy_run.argtypes = [vp, vp, i32, i32]
+    lib.pce_energy_fetch.argtypes = [vp, vp]
+    lib.pce_lufs_run.argtypes = [vp, vp, i32]
+    lib.pce_lufs_fetch.argtypes = [vp, vp, vp]
+    lib.pce_pitch_plan.argtypes = [vp, C.POINTER(PitchParams), vp, i32, vp, vp]
+    lib.pce_pitch_run.argtypes = [vp, C.POINTER(PitchParams), vp, i32]
+    lib.pce_pitch_fetch.argtypes = [vp, vp, vp, vp]
+    lib.pce_stft_db_run.argtypes = [vp, i32, i32]
+    lib.pce_stft_db_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.pce_stft_db_fetch.argtypes = [vp, i32, vp]
+    lib.pce_stft_db_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    lib.pce_profile_enable.argtypes = [vp, C.c_int]
+    lib.pce_profile_reset.argtypes = [vp]
+    lib.pce_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.pce_kernel_name.argtypes = [C.c_int]; lib.pce_kernel_name.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("pce_create",):
+            fn.restype = C.c_int
+    return lib
+
+
+def make_slices(clips, begins, ends, x1=None) -> np.ndarray:
+    """Pack parallel arrays into the ``pce_slice`` layout."""
+    n = len(clips)
+    s = np.zeros(n, dtype=SLICE_DTYPE)
+    s["clip"] = clips; s["begin"] = begins; s["end"] = ends
+    if x1 is not None:
+        s["x1"] = x1
+    return s
+
+
+class ProsodyEngine:
+    """One GPU context.  ``device``: HIP device index; ``stream``: optional ``hipStream_t`` handle
+    (e.g. ``torch.cuda.current_stream().cuda_stream``) to enqueue on."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = load_library()
+        err = C.create_string_buffer(512)
+        self._ctx = self._lib.pce_create(int(device), C.c_void_p(stream) if stream else None, err, len(err))
+        if not self._ctx:
+            raise PceError(f"pce_create failed: {err.value.decode(errors='replace')}")
+        self.rate = 0
+        self.clip_lengths = np.zeros(0, dtype=np.int64)
+        self._keep = []
+
+    # ---------------------------------------------------------------- plumbing
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pce_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise PceError(f"libpce status {rc}: {self._lib.pce_last_error(self._ctx).decode(errors='replace')}")
+
+    def sync(self):
+        self._check(self._lib.pce_sync(self._ctx))
+
+    def device_info(self):
+        name = C.create_string_buffer(256); cus = C.c_int32(); hbm = C.c_int64()
+        self._check(self._lib.pce_device_info(self._ctx, name, len(name), C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    # ---------------------------------------------------------------- residency
+    def upload(self, clips, rate: int):
+        """Upload a batch: ``clips`` is a list of int16 1-D arrays (one per utterance)."""
+        clips = [np.ascontiguousarray(c, dtype=np.int16).reshape(-1) for c in clips]
+        lens = np.array([len(c) for c in clips], dtype=np.int64)
+        offsets = np.zeros(len(clips) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        pcm = np.concatenate(clips) if clips else np.zeros(0, dtype=np.int16)
+        if pcm.size == 0:
+            pcm = np.zeros(1, dtype=np.int16)
+        self._check(self._lib.pce_upload_pcm_s16(self._ctx, pcm.ctypes.data, offsets.ctypes.data, len(clips), int(rate)))
+        self.rate = int(rate); self.clip_lengths = lens; self.offsets = offsets
+        return self
+
+    def bind_device(self, device_ptr: int, offsets, rate: int, keepalive=None):
+        """Zero-copy: adopt int16 PCM already resident in HBM (e.g. a torch tensor's ``data_ptr()``)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self._check(self._lib.pce_bind_pcm_s16_device(self._ctx, C.c_void_p(device_ptr), offsets.ctypes.data,
+                                                       len(offsets) - 1, int(rate)))
+        self.rate = int(rate); self.clip_lengths = np.diff(offsets); self.offsets = offsets
+        self._keep = [keepalive]
+        return self
+
+    def whole_clip_slices(self) -> np.ndarray:
+        n = len(self.clip_lengths)
+        return make_slices(np.arange(n), np.zeros(n, dtype=np.int64), self.clip_lengths, np.full(n, 0.5 / self.rate))
+
+    # ---------------------------------------------------------------- ops
+    @staticmethod
+    def _slices(s) -> np.ndarray:
+        s = np.ascontiguousarray(s, dtype=SLICE_DTYPE)
+        return s
+
+    def energy_run(self, slices, loud_threshold: int = 500):
+        s = self._slices(slices); self._en_n = len(s)
+        self._check(self._lib.pce_energy_run(self._ctx, s.ctypes.data, len(s), int(loud_threshold)))
+
+    def energy_fetch(self) -> np.ndarray:
+        out = np.zeros(self._en_n, dtype=ENERGY_DTYPE)
+        self._check(self._lib.pce_energy_fetch(self._ctx, out.ctypes.data))
+        return out
+
+    def energy(self, slices, loud_threshold: int = 500) -> np.ndarray:
+        self.energy_run(slices, loud_threshold)
+        return self.energy_fetch()
+
+    def lufs_run(self, slices):
+        s = self._slices(slices); self._lu_n = len(s)
+        self._check(self._lib.pce_lufs_run(self._ctx, s.ctypes.data, len(s)))
+
+    def lufs_fetch(self):
+        out = np.zeros(self._lu_n, dtype=np.float64); st = np.zeros(self._lu_n, dtype=np.int32)
+        self._check(self._lib.pce_lufs_fetch(self._ctx, out.ctypes.data, st.ctypes.data))
+        return out, st
+
+    def lufs(self, slices):
+        self.lufs_run(slices)
+        return self.lufs_fetch()
+
+    def pitch_plan(self, slices, params: PitchParams):
+        s = self._slices(slices)
+        off = np.zeros(len(s) + 1, dtype=np.int64); st = np.zeros(len(s), dtype=np.int32)
+        self._check(self._lib.pce_pitch_plan(self._ctx, C.byref(params), s.ctypes.data, len(s), off.ctypes.data, st.ctypes.data))
+        return off, st
+
+    def pitch_run(self, slices, params: PitchParams):
+        s = self._slices(slices); self._pi_slices = s; self._pi_params = params
+        self._check(self._lib.pce_pitch_run(self._ctx, C.byref(params), s.ctypes.data, len(s)))
+
+    def pitch_fetch(self, want_f0=True, want_strength=False):
+        s = self._pi_slices
+        off, _ = self.pitch_plan(s, self._pi_params)
+        total = int(off[-1])
+        f0 = np.zeros(total, dtype=np.float64) if want_f0 else None
+        sg = np.zeros(total, dtype=np.float64) if want_strength else None
+        summ = np.zeros(len(s), dtype=SUMMARY_DTYPE)
+        self._check(self._lib.pce_pitch_fetch(self._ctx, f0.ctypes.data if want_f0 else None,
+                                              sg.ctypes.data if want_strength else None, summ.ctypes.data))
+        return {"frame_offsets": off, "f0": f0, "strength": sg, "summary": summ}
+
+    def pitch(self, slices, params: PitchParams, want_f0=True, want_strength=False):
+        self.pitch_run(slices, params)
+        return self.pitch_fetch(want_f0, want_strength)
+
+    def stft_db_run(self, n_fft: int = 1024, hop: int = 256):
+        self._check(self._lib.pce_stft_db_run(self._ctx, int(n_fft), int(hop)))
+
+    def stft_db_fetch(self, clip: int) -> np.ndarray:
+        nb = C.c_int32(); nf = C.c_int32()
+        self._check(self._lib.pce_stft_db_shape(self._ctx, int(clip), C.byref(nb), C.byref(nf)))
+        out = np.zeros((nb.value, nf.value), dtype=np.float32)
+        self._check(self._lib.pce_stft_db_fetch(self._ctx, int(clip), out.ctypes.data))
+        return out
+
+    def stft_db_device(self):
+        p = C.c_void_p(); n = C.c_int64()
+        self._check(self._lib.pce_stft_db_device(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---------------------------------------------------------------- measurement
+    def profile_enable(self, on=True):
+        self._check(self._lib.pce_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.pce_profile_reset(self._ctx))
+
+    def profile(self) -> dict:
+        out = {}
+        for i, name in enumerate(KERNEL_IDS):
+            ms = C.c_double(); n = C.c_int64()
+            self._check(self._lib.pce_profile_get(self._ctx, i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[name] = {"total_ms": ms.value, "launches": n.value}
+        return out
