@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the prosody hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 10 s 16 kHz
+mono clips, resident in HBM as int16 before the timed region.  One step = one pass of the
+hot path over the batch:
+    k_energy (gate/peak/RMS integers)  +  BS.1770 LUFS  +  Praat-AC F0 (150-600 Hz) with path
+    finding and voiced median  +  STFT-dB 1024/256,
+followed by the fetch of the per-utterance statistics (a few KB) and, for N > 1, the single
+all-gather of those statistics (RCCL).  The 329 MB STFT-dB result stays in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line on rank 0.  `value` = audio seconds processed by all ranks / wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(kernel: str, n_clips: int, n_samples: int, n_pitch_frames: int, n_stft_frames: int) -> float:
+    """Algorithmic bytes of ONE launch (PCM 2 B/sample read once per
+    kernel; F0 8 B/frame; STFT-dB 513*4 B/frame; O(1) per clip for the scalar outputs)."""
+    pcm = 2.0 * n_samples * n_clips
+    return {
+        "k_energy": pcm,
+        "k_lufs_pass1": pcm, "k_lufs_pass2": pcm,
+        "k_lufs_scan": 0.0, "k_lufs_gate": 0.0,
+        "k_pitch_frames": pcm + 8.0 * n_pitch_frames * n_clips,
+        "k_pitch_path": 8.0 * n_pitch_frames * n_clips, "k_pitch_median": 8.0 * n_pitch_frames * n_clips,
+        "k_stft_max": pcm,
+        "k_stft_db": pcm + 513 * 4.0 * n_stft_frames * n_clips,
+    }.get(kernel, 0.0)
+
+
+def cpu_baseline(clips, rate, budget_clips):
+    """The CPU oracle ("port": C double-precision restatement, 1 thread) on a bounded sample."""
+    from oracle import oracle as O
+    sample = clips[:budget_clips]
+    t0 = time.perf_counter()
+    for c in sample:
+        x = c.astype(np.float64)
+        O.gate_check(c)
+        O.rms_db_int16_wrapped(c)
+        O.lufs_c(x, rate)
+        f0 = O.pitch_ac(x / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+        v = f0[f0 > 0]
+        _ = float(np.median(v)) if v.size else 0.0
+        O.stft_db(c.astype(np.float32) / 32768.0)
+    dt = time.perf_counter() - t0
+    secs = sum(len(c) for c in sample) / rate
+    return {"value": secs / dt, "unit": "audio-seconds/sec", "cores": 1, "kind": "port",
+            "sample": f"{len(sample)} of the same synthetic 10 s clips, oracle/pce_oracle.c + numpy, {dt:.1f} s of CPU time"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-clips", type=int, default=256, help="clips timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import prosody_control_french_tts_amd as pkg
+    from prosody_control_french_tts_amd import shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    rate = 16000
+    n_samples = int(round(args.seconds * rate))
+
+    # synthetic data of the workload's shape; rank r owns clips [r*clips, (r+1)*clips) (weak scaling)
+    clips = synth.synth_batch(args.clips, args.seconds, rate, first=rank * args.clips)
+
+    eng = pkg.ProsodyEngine(local_rank)
+    eng.upload(clips, rate)                      # inputs resident in HBM before the timed region
+    sl = eng.whole_clip_slices()
+    params = pkg.PitchParams.praat(150.0, 600.0)
+    off, _ = eng.pitch_plan(sl, params)
+    n_pitch_frames = int(off[1] - off[0])
+    n_stft_frames = 1 + n_samples // 256
+
+    def step():
+        eng.energy_run(sl, 500)
+        eng.lufs_run(sl)
+        eng.pitch_run(sl, params)
+        eng.stft_db_run(1024, 256)
+        en = eng.energy_fetch()
+        lu, _ = eng.lufs_fetch()
+        pi = eng.pitch_fetch(want_f0=False)["summary"]
+        # per-utterance record: [median F0, LUFS, rms, peak, silence ratio, duration, n_voiced]
+        rec = np.stack([pi["median_f0"], lu, np.sqrt(en["sum_sq"] / np.maximum(en["n"], 1)), en["peak_abs"].astype(np.float64),
+                        1.0 - en["n_loud"] / np.maximum(en["n"], 1), en["n"] / float(rate), pi["n_voiced"].astype(np.float64)], axis=1)
+        return shard.allgather_records(rec)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        eng.profile_enable(True)
+        eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile() if not args.no_profile else {}
+    eng.profile_enable(False)
+
+    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+    audio_seconds = args.clips * args.seconds * world * args.steps
+    assert rec.shape == (args.clips * world, 7)
+
+    if rank == 0:
+        kernels = []
+        for name, p in prof.items():
+            avg_ms = p["total_ms"] / p["launches"]
+            ab = algorithmic_bytes(name, args.clips, n_samples, n_pitch_frames, n_stft_frames)
+            kernels.append({"kernel": name, "avg_ms": avg_ms, "launches_per_step": p["launches"] / args.steps,
+                            "ms_per_step": p["total_ms"] / args.steps, "algorithmic_bytes": ab,
+                            "achieved_GBs": ab / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None})
+        kernels.sort(key=lambda k: -k["ms_per_step"])
+        roofline = None
+        if kernels:
+            k0 = kernels[0]
+            roofline = {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": k0["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                        "note": "dominant kernel by device time; k_pitch_frames is fp64-VALU/LDS bound (about 1e3 flop per "
+                                "algorithmic byte), see DESIGN.md; per-kernel figures in `kernels`"}
+        cpu = cpu_baseline(clips, rate, args.cpu_clips) if args.cpu_clips > 0 else None
+        info = eng.device_info()
+        print(json.dumps({
+            "metric": "audio-seconds/sec prosody+align throughput, 16 kHz French",
+            "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, "
+                                   "energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256; "
+                                   "Whisper-encoder alignment (C3) not included",
+                       "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
+                       "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip"},
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "device": info["name"], "host_cores": os.cpu_count(),
+        }))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
