@@ -84,29 +84,55 @@ __global__ void k_lufs_pass1(const int16_t *__restrict__ pcm, const LuSlice *__r
     o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
 }
 
-__global__ void k_lufs_scan(const LuSlice *__restrict__ slices, const LuChunk *__restrict__ chunks, int n_slices,
-                            const double *__restrict__ apow /* [LU_LMAX+1][16] */, const double *__restrict__ state_end,
-                            double *__restrict__ state_init)
+__device__ __forceinline__ double lu_readlane_f64(double v, int src)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// One wavefront per slice.  The 64 lanes fetch 64 chunk end-states with one coalesced load
+// each; the (inherently sequential) propagation then runs wave-uniform with v_readlane
+// broadcasts, so the chain never waits on memory.
+__global__ __launch_bounds__(64) void k_lufs_scan(const LuSlice *__restrict__ slices, const LuChunk *__restrict__ chunks, int n_slices,
+                                                  const double *__restrict__ apow /* [LU_LMAX+1][16] */,
+                                                  const double *__restrict__ state_end, double *__restrict__ state_init)
+{
+    const int i = blockIdx.x;
     if (i >= n_slices) return;
+    const int lane = threadIdx.x;
     const LuSlice s = slices[i];
-    double st[4] = {0.0, 0.0, 0.0, 0.0};
+    double st0 = 0.0, st1 = 0.0, st2 = 0.0, st3 = 0.0;
     double m[16]; int cur_len = -1;
-    for (int c = 0; c < s.n_chunks; c++) {
-        const size_t ci = (size_t)(s.first_chunk + c);
-        double *o = state_init + 4 * ci;
-        o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
-        const int len = chunks[ci].len;
-        if (len != cur_len) {
-            for (int q = 0; q < 16; q++) m[q] = apow[(size_t)len * 16 + q];
-            cur_len = len;
+    for (int c0 = 0; c0 < s.n_chunks; c0 += 64) {
+        const int cnt = min(64, s.n_chunks - c0);
+        const size_t ci = (size_t)(s.first_chunk + c0 + lane);
+        const bool valid = lane < cnt;
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0; int len = 0;
+        if (valid) {
+            const double *e = state_end + 4 * ci;
+            e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3];
+            len = chunks[ci].len;
         }
-        const double *e = state_end + 4 * ci;
-        double nx[4];
-        for (int r = 0; r < 4; r++)
-            nx[r] = (((m[4 * r] * st[0] + m[4 * r + 1] * st[1]) + m[4 * r + 2] * st[2]) + m[4 * r + 3] * st[3]) + e[r];
-        st[0] = nx[0]; st[1] = nx[1]; st[2] = nx[2]; st[3] = nx[3];
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+        for (int q = 0; q < cnt; q++) {
+            if (lane == q) { o0 = st0; o1 = st1; o2 = st2; o3 = st3; }
+            const int lq = __builtin_amdgcn_readlane(len, q);
+            if (lq != cur_len) {
+                for (int t = 0; t < 16; t++) m[t] = apow[(size_t)lq * 16 + t];
+                cur_len = lq;
+            }
+            const double q0 = lu_readlane_f64(e0, q), q1 = lu_readlane_f64(e1, q), q2 = lu_readlane_f64(e2, q), q3 = lu_readlane_f64(e3, q);
+            const double n0 = (((m[0] * st0 + m[1] * st1) + m[2] * st2) + m[3] * st3) + q0;
+            const double n1 = (((m[4] * st0 + m[5] * st1) + m[6] * st2) + m[7] * st3) + q1;
+            const double n2 = (((m[8] * st0 + m[9] * st1) + m[10] * st2) + m[11] * st3) + q2;
+            const double n3 = (((m[12] * st0 + m[13] * st1) + m[14] * st2) + m[15] * st3) + q3;
+            st0 = n0; st1 = n1; st2 = n2; st3 = n3;
+        }
+        if (valid) {
+            double *o = state_init + 4 * ci;
+            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+        }
     }
 }
 
@@ -123,36 +149,47 @@ __global__ void k_lufs_pass2(const int16_t *__restrict__ pcm, const LuSlice *__r
     energy[i] = lu_run<true>(pcm, s, ch, k, lu_peak(peaks, pstride, ch.slice), st);
 }
 
-__global__ void k_lufs_gate(const LuSlice *__restrict__ slices, const LuBlock *__restrict__ blocks, int n_slices, LuCoef k,
-                            const double *__restrict__ energy, double *__restrict__ zbuf, double *__restrict__ lufs)
+__device__ __forceinline__ double lu_wave_sum(double v)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One wavefront per slice: lanes own gating blocks (block energies = sums of whole chunks,
+// in chunk order), the two gated means are butterfly reductions.
+__global__ __launch_bounds__(64) void k_lufs_gate(const LuSlice *__restrict__ slices, const LuBlock *__restrict__ blocks, int n_slices, LuCoef k,
+                                                  const double *__restrict__ energy, double *__restrict__ zbuf, double *__restrict__ lufs)
+{
+    const int i = blockIdx.x;
     if (i >= n_slices) return;
+    const int lane = threadIdx.x;
     const LuSlice s = slices[i];
-    if (s.status != PCE_SLICE_OK) { lufs[i] = nan(""); return; }
+    if (s.status != PCE_SLICE_OK) { if (lane == 0) lufs[i] = nan(""); return; }
     const double *en = energy + s.first_chunk;
     double *z = zbuf + s.first_block;
     const double gamma_a = -70.0;
-    double sum = 0.0; int cnt = 0;
-    for (int j = 0; j < s.n_blocks; j++) {
+    double sum = 0.0, cnt = 0.0;
+    for (int j = lane; j < s.n_blocks; j += 64) {
         const LuBlock b = blocks[s.first_block + j];
         double e = 0.0;
         for (int c = b.c0; c < b.c1; c++) e += en[c];
         const double zj = k.inv_norm * e;
         z[j] = zj;
         const double lj = -0.691 + 10.0 * log10(zj);
-        if (lj >= gamma_a) { sum += zj; cnt++; }
+        if (lj >= gamma_a) { sum += zj; cnt += 1.0; }
     }
-    const double zavg1 = cnt ? sum / (double)cnt : nan("");
+    sum = lu_wave_sum(sum); cnt = lu_wave_sum(cnt);
+    const double zavg1 = cnt > 0.0 ? sum / cnt : nan("");
     const double gamma_r = -0.691 + 10.0 * log10(zavg1) - 10.0;
-    sum = 0.0; cnt = 0;
-    for (int j = 0; j < s.n_blocks; j++) {
+    sum = 0.0; cnt = 0.0;
+    for (int j = lane; j < s.n_blocks; j += 64) {
         const double zj = z[j];
         const double lj = -0.691 + 10.0 * log10(zj);
-        if (lj > gamma_r && lj > gamma_a) { sum += zj; cnt++; }
+        if (lj > gamma_r && lj > gamma_a) { sum += zj; cnt += 1.0; }
     }
-    const double zavg2 = cnt ? sum / (double)cnt : 0.0;
-    lufs[i] = -0.691 + 10.0 * log10(zavg2);
+    sum = lu_wave_sum(sum); cnt = lu_wave_sum(cnt);
+    const double zavg2 = cnt > 0.0 ? sum / cnt : 0.0;
+    if (lane == 0) lufs[i] = -0.691 + 10.0 * log10(zavg2);
 }
 
 // pyloudnorm.IIRfilter.generate_coefficients for the two K-weighting stages
@@ -317,7 +354,7 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
         }
         {
             KernelTimer t(c, PCE_K_LUFS_SCAN);
-            hipLaunchKernelGGL(k_lufs_scan, dim3((unsigned)div_up(n, 64)), dim3(64), 0, c->stream,
+            hipLaunchKernelGGL(k_lufs_scan, dim3((unsigned)n), dim3(64), 0, c->stream,
                                c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), (int)n, c->lu_pow.as<double>(),
                                c->lu_state_end.as<double>(), c->lu_state_init.as<double>());
         }
@@ -330,7 +367,7 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
     }
     if (n > 0) {
         KernelTimer t(c, PCE_K_LUFS_GATE);
-        hipLaunchKernelGGL(k_lufs_gate, dim3((unsigned)div_up(n, 64)), dim3(64), 0, c->stream,
+        hipLaunchKernelGGL(k_lufs_gate, dim3((unsigned)n), dim3(64), 0, c->stream,
                            c->lu_meta.as<LuSlice>(), c->lu_blocks.as<LuBlock>(), (int)n, k, c->lu_energy.as<double>(),
                            c->lu_zbuf.as<double>(), c->lu_out.as<double>());
     }

@@ -74,11 +74,13 @@ constexpr double PI_D = 3.1415926535897932384626433832795028841972;
 constexpr double LOG2E_D = 1.4426950408889634073599246810018921374266;
 constexpr int PI_WPB = 4;                 // waves (= frames) per block in k_pitch_frames
 constexpr int PI_MAXC = 16;               // candidates per frame the kernels can hold
-constexpr int PATH_TILE = 64;             // frames staged per LDS tile in k_pitch_path
+constexpr int PATH_TILE = 64;
+constexpr int RF_LISTS = 256;             // independent candidate lists (one hot counter would serialise in L2)
+constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte lines             // frames staged per LDS tile in k_pitch_path
 
 struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
-    int nsp, hsp, nw, hw, maxlag, bix, maxc, xs_len, rr_len, pad;
+    int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len;
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -86,6 +88,7 @@ struct PiSlice {
     int32_t n_frames, status;
 };
 struct PiWork { int32_t slice, frame0; };
+struct RefineItem { long long frame; int slot; int imax; };
 
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
@@ -144,55 +147,79 @@ __device__ double sinc_wave(const double *y, int nx, double x, int maxDepth, int
     return wave_sum_f64(acc);
 }
 
-// Praat NUMimproveExtremum (maximum) = NUMminimize_brent on -sinc, tol 1e-10, <= 60 iterations.
-__device__ double improve_maximum_wave(const double *y, int nx, int ixmid, int depth, double *ixmid_real, int lane)
+// ---------------------------------------------------------------------------
+// fp64 autocorrelation by FFT, one wavefront per frame, entirely in LDS.
+// The zero-padded real frame x[0..N) is read as M = N/2 complex points z[n] = x[2n] + i x[2n+1]
+// (the staging buffer IS that array), transformed with Stockham radix-4 (+ one radix-2)
+// passes that ping-pong between two LDS buffers, untangled into the power spectrum
+// P[k] = |X[k]|^2, re-tangled (P is real and even) and sent through the same forward
+// transform again: ac[2n] = Re Y[n], ac[2n+1] = -Im Y[n] (common positive scale dropped;
+// it cancels in r[k] = ac[k] / (ac[0] windowR[k])).  Praat itself takes this route
+// (NUMfft_forward / power / NUMfft_backward in Sound_to_Pitch.cpp); N = nsampFFT.
+// LDS index padding: one complex per 8 keeps the stride-4 Stockham stores conflict-free.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int ZP(int p) { return p + (p >> 3); }
+__device__ __forceinline__ double2 cmul_f64(double2 a, double2 w)
 {
-    if (ixmid <= 1) { *ixmid_real = 1.0; return y[0]; }
-    if (ixmid >= nx) { *ixmid_real = (double)nx; return y[nx - 1]; }
-    double a = (double)(ixmid - 1), b = (double)(ixmid + 1);
-    const double golden = 1.0 - 0.6180339887498948482045868343656381177203;
-    const double sqrt_epsilon = 1.4901161193847656e-08;     // sqrt(DBL_EPSILON)
-    const double tol = 1e-10;
-    double v = a + golden * (b - a);
-    double fv = -sinc_wave(y, nx, v, depth, lane);
-    double x = v, w = v, fx = fv, fw = fv;
-    for (int iter = 1; iter <= 60; iter++) {
-        const double range = b - a;
-        const double middle_range = (a + b) / 2.0;
-        const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.0;
-        if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) break;
-        double new_step = golden * (x < middle_range ? b - x : a - x);
-        if (fabs(x - w) >= tol_act) {
-            double t = (x - w) * (fx - fv);
-            double q = (x - v) * (fx - fw);
-            double p = (x - v) * q - (x - w) * t;
-            q = 2.0 * (q - t);
-            if (q > 0.0) p = -p; else q = -q;
-            if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
-                new_step = p / q;
-        }
-        if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
-        const double t = x + new_step;
-        const double ft = -sinc_wave(y, nx, t, depth, lane);
-        if (ft <= fx) {
-            if (t < x) b = x; else a = x;
-            v = w; w = x; x = t;
-            fv = fw; fw = fx; fx = ft;
+    return make_double2(fma(a.x, w.x, -(a.y * w.y)), fma(a.x, w.y, a.y * w.x));
+}
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// forward DFT of M points (exp(-2 pi i ...)); returns the buffer holding the result
+__device__ double2 *fft_wave(double2 *src, double2 *dst, int M, const double2 *__restrict__ twM, int lane)
+{
+    int Ns = 1;
+    while (Ns < M) {
+        if (M / Ns >= 4) {
+            const int nb = M >> 2, tws = M / (Ns << 2);
+            for (int b = lane; b < nb; b += 64) {
+                const int k = b & (Ns - 1);
+                double2 a0 = src[ZP(b)], a1 = src[ZP(b + nb)], a2 = src[ZP(b + 2 * nb)], a3 = src[ZP(b + 3 * nb)];
+                if (Ns > 1) {
+                    a1 = cmul_f64(a1, twM[k * tws]);
+                    a2 = cmul_f64(a2, twM[2 * k * tws]);
+                    a3 = cmul_f64(a3, twM[3 * k * tws]);
+                }
+                const double2 b0 = make_double2(a0.x + a2.x, a0.y + a2.y), b1 = make_double2(a0.x - a2.x, a0.y - a2.y);
+                const double2 b2 = make_double2(a1.x + a3.x, a1.y + a3.y);
+                const double2 b3 = make_double2(a1.y - a3.y, -(a1.x - a3.x));          // (a1 - a3) * (-i)
+                const int base = ((b - k) << 2) + k;
+                dst[ZP(base)] = make_double2(b0.x + b2.x, b0.y + b2.y);
+                dst[ZP(base + Ns)] = make_double2(b1.x + b3.x, b1.y + b3.y);
+                dst[ZP(base + 2 * Ns)] = make_double2(b0.x - b2.x, b0.y - b2.y);
+                dst[ZP(base + 3 * Ns)] = make_double2(b1.x - b3.x, b1.y - b3.y);
+            }
+            Ns <<= 2;
         } else {
-            if (t < x) a = t; else b = t;
-            if (ft <= fw || w == x) { v = w; w = t; fv = fw; fw = ft; }
-            else if (ft <= fv || v == x || v == w) { v = t; fv = ft; }
+            const int nb = M >> 1, tws = M / (Ns << 1);
+            for (int b = lane; b < nb; b += 64) {
+                const int k = b & (Ns - 1);
+                const double2 a0 = src[ZP(b)];
+                double2 a1 = src[ZP(b + nb)];
+                if (Ns > 1) a1 = cmul_f64(a1, twM[k * tws]);
+                const int base = ((b - k) << 1) + k;
+                dst[ZP(base)] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                dst[ZP(base + Ns)] = make_double2(a0.x - a1.x, a0.y - a1.y);
+            }
+            Ns <<= 1;
         }
+        wave_sync();
+        double2 *t = src; src = dst; dst = t;
     }
-    *ixmid_real = x;
-    return -fx;
+    return src;
 }
 
 __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
     const int16_t *__restrict__ pcm, const PiSlice *__restrict__ slices, const PiWork *__restrict__ work, int n_work,
     PiParams P, const double *__restrict__ window, const double *__restrict__ windowR,
+    const double2 *__restrict__ twM /* exp(-2 pi i m / M), m < M */, const double2 *__restrict__ twN /* exp(-2 pi i k / N), k <= M */,
     const long long *acc_sum, const int *acc_hi, const int *acc_lo, size_t acc_stride,
-    double *__restrict__ cand /* [frames][32]: 16 freq, 16 strength */, int *__restrict__ ncand, double *__restrict__ intensity)
+    double *__restrict__ cand /* [frames][32]: 16 freq, 16 strength */, int *__restrict__ ncand, double *__restrict__ intensity,
+    double *__restrict__ rr_out /* [frames][rr_len] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
+    unsigned int list_cap)
 {
     extern __shared__ double lds[];
     // XCD-aware remap: consecutive work items (overlapping windows of one slice) go to one XCD's L2
@@ -205,8 +232,10 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
     const PiSlice s = slices[wk.slice];
     const int iframe = wk.frame0 + wv;                  // 0-based
     if (iframe >= s.n_frames) return;
-    double *xs = lds + (size_t)wv * (size_t)(P.xs_len + P.rr_len);
-    double *rr = xs + P.xs_len;                         // rr[bix + k] = r[k], k in [-bix, bix]
+    double2 *bufA = reinterpret_cast<double2 *>(lds) + (size_t)wv * (size_t)(2 * P.zlen);
+    double2 *bufB = bufA + P.zlen;
+    double *xr = reinterpret_cast<double *>(bufA);      // real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
+    const int M = P.nfft >> 1;
     const int64_t fidx = s.frame_off + iframe;
 
     // global mean / peak of the slice from the exact integer accumulators
@@ -231,65 +260,70 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
 
     // stage raw samples (exact in fp64) and the integer local sum
     int isum = 0;
-    for (int j = lane; j < P.xs_len; j += 64) {
+    for (int j = lane; j < P.nfft; j += 64) {
         int v = 0;
         if (j < P.nw) {
             const int64_t rel = ws + j, cc = s.begin + rel;
             if (rel >= 0 && rel < s.nx && cc >= 0 && cc < s.clip_len) v = (int)pcm[s.clip_off + cc];
             if (rel >= m0 && rel <= m1) isum += v;
         }
-        xs[j] = (double)v / 32768.0;
+        xr[2 * ZP(j >> 1) + (j & 1)] = (double)v / 32768.0;
     }
     isum = wave_sum_i32(isum);
     const double localMean = ((double)isum / 32768.0) / (double)(2 * P.nsp);
     double lpk = 0.0;
     const int pk0 = max(P.hw + 1 - P.hsp, 1), pk1 = min(P.hw + P.hsp, P.nw);   // 1-based inclusive
     for (int j = lane; j < P.nw; j += 64) {
-        const double f = (xs[j] - localMean) * window[j];
-        xs[j] = f;
+        const int a = 2 * ZP(j >> 1) + (j & 1);
+        const double f = (xr[a] - localMean) * window[j];
+        xr[a] = f;
         if (j + 1 >= pk0 && j + 1 <= pk1) lpk = fmax(lpk, fabs(f));
     }
     const double localPeak = wave_max_f64(lpk);
     const double inten = localPeak > globalPeak ? 1.0 : localPeak / globalPeak;
 
+    double *rr = nullptr;                                // rr[bix + k] = r[k], k in [-bix, bix]
     // candidate registers: lane q holds candidate q (0 = the voiceless candidate)
     double c_f = 0.0, c_s = 0.0; int c_i = 0; int n = 1;
 
     if (localPeak != 0.0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        // autocorrelation by direct summation; lanes own lags lane, lane+64, ... (4 per pass)
-        for (int base = 0; base <= P.bix; base += 256) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const int k0 = base + lane;
-            const int jn = P.nw - base;                          // beyond this every product hits the zero padding
-            const double *xk = xs + k0;
-            for (int j = 0; j < jn; j++) {
-                const double a = xs[j];
-                a0 = fma(a, xk[j], a0);
-                a1 = fma(a, xk[j + 64], a1);
-                a2 = fma(a, xk[j + 128], a2);
-                a3 = fma(a, xk[j + 192], a3);
-            }
-            if (k0 <= P.bix) rr[P.bix + k0] = a0;
-            if (k0 + 64 <= P.bix) rr[P.bix + k0 + 64] = a1;
-            if (k0 + 128 <= P.bix) rr[P.bix + k0 + 128] = a2;
-            if (k0 + 192 <= P.bix) rr[P.bix + k0 + 192] = a3;
+        wave_sync();
+        // forward transform of the packed frame
+        double2 *Z = fft_wave(bufA, bufB, M, twM, lane);
+        double2 *W = (Z == bufA) ? bufB : bufA;
+        // power spectrum of the real frame, re-tangled for the second (inverse) transform
+        for (int k = lane; k <= (M >> 1); k += 64) {
+            const double2 zk = Z[ZP(k & (M - 1))], zm = Z[ZP((M - k) & (M - 1))];
+            const double2 w = twN[k];                                     // (cos, -sin)
+            const double2 ez = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+            const double2 oz = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+            const double2 t = cmul_f64(oz, w);
+            const double xr1 = ez.x + t.x, xi1 = ez.y + t.y, xr2 = ez.x - t.x, xi2 = ez.y - t.y;
+            const double pk = fma(xr1, xr1, xi1 * xi1), pm = fma(xr2, xr2, xi2 * xi2);
+            const double e = 0.5 * (pk + pm), d = 0.5 * (pk - pm);
+            const double c = w.x, sn = -w.y;
+            W[ZP(k & (M - 1))] = make_double2(e - d * sn, -(d * c));
+            if (k != 0 && k != M - k) W[ZP(M - k)] = make_double2(e + d * sn, -(d * c));
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const double ac0 = rr[P.bix];
+        wave_sync();
+        double2 *Y = fft_wave(W, Z, M, twM, lane);
+        rr = reinterpret_cast<double *>((Y == bufA) ? bufB : bufA);       // the free buffer holds r[-bix..bix]
+        const double ac0 = Y[0].x;
         for (int k = lane + 1; k <= P.bix; k += 64) {
-            const double v = rr[P.bix + k] / (ac0 * windowR[k]);
+            const double2 y = Y[ZP(k >> 1)];
+            const double ack = (k & 1) ? -y.y : y.x;
+            const double v = ack / (ac0 * windowR[k]);
             rr[P.bix + k] = v; rr[P.bix - k] = v;
         }
         if (lane == 0) rr[P.bix] = 1.0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
 
         const int ynx = 2 * P.bix + 1;
         const int lim = min(P.maxlag, P.bix);
         const double half_vt = 0.5 * P.voicing_thr;
+        // count the local maxima first: with at most maxc-1 of them (the common case) every
+        // maximum becomes a candidate and the first-pass strength is never consulted.
+        int total = 0;
         for (int base = 2; base < lim; base += 64) {
             const int i = base + lane;
             bool pred = false;
@@ -297,52 +331,318 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
                 const double r0 = rr[P.bix + i], rm = rr[P.bix + i - 1], rp = rr[P.bix + i + 1];
                 pred = r0 > half_vt && r0 > rm && r0 >= rp;
             }
-            unsigned long long mask = __ballot(pred);
-            while (mask) {
-                const int bpos = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int im = base + bpos;
-                const double r0 = rr[P.bix + im], rm = rr[P.bix + im - 1], rp = rr[P.bix + im + 1];
-                const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
-                const double fmx = 1.0 / P.dx / ((double)im + dr / d2r);
-                double smx = sinc_wave(rr, ynx, 1.0 / P.dx / fmx + (double)(P.bix + 1), 30, lane);
-                if (smx > 1.0) smx = 1.0 / smx;
-                int place = -1;
-                if (n < P.maxc) {
-                    place = n++;
-                } else {
-                    // weakest candidate so far among 1..maxc-1 (first minimum wins)
-                    double ls = c_s - P.octave_cost * (log(P.min_pitch / c_f) * LOG2E_D);
-                    int li = lane;
-                    if (lane < 1 || lane >= P.maxc) { ls = 1e300; li = 1 << 20; }
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const double os = __shfl_xor(ls, off, 64);
-                        const int oi = __shfl_xor(li, off, 64);
-                        if (os < ls || (os == ls && oi < li)) { ls = os; li = oi; }
-                    }
-                    double weakest = 2.0;
-                    if (ls < weakest) { weakest = ls; place = li; }
-                    if (smx - P.octave_cost * (log(P.min_pitch / fmx) * LOG2E_D) <= weakest) place = -1;
+            const unsigned long long mask = __ballot(pred);
+            const int here = __popcll(mask);
+            if (total + here <= P.maxc - 1) {
+                // the lane that owns slot (1 + total + q) takes the lag of the q-th maximum of this round
+                const int need = lane - 1 - total;
+                if (need >= 0 && need < here) {
+                    unsigned long long m = mask;
+                    for (int q = 0; q < need; q++) m &= m - 1;
+                    c_i = base + __ffsll((long long)m) - 1;
                 }
-                if (place >= 0 && lane == place) { c_f = fmx; c_s = smx; c_i = im; }
+            }
+            total += __popcll(mask);
+        }
+        if (total <= P.maxc - 1) {
+            n = 1 + total;
+        } else {
+            // rare: more maxima than candidate slots -> Praat's replacement rule needs first-pass strengths
+            c_i = 0;
+            for (int base = 2; base < lim; base += 64) {
+                const int i = base + lane;
+                bool pred = false;
+                if (i < lim) {
+                    const double r0 = rr[P.bix + i], rm = rr[P.bix + i - 1], rp = rr[P.bix + i + 1];
+                    pred = r0 > half_vt && r0 > rm && r0 >= rp;
+                }
+                unsigned long long mask = __ballot(pred);
+                while (mask) {
+                    const int bpos = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int im = base + bpos;
+                    const double r0 = rr[P.bix + im], rm = rr[P.bix + im - 1], rp = rr[P.bix + im + 1];
+                    const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
+                    const double fmx = 1.0 / P.dx / ((double)im + dr / d2r);
+                    double smx = sinc_wave(rr, ynx, 1.0 / P.dx / fmx + (double)(P.bix + 1), 30, lane);
+                    if (smx > 1.0) smx = 1.0 / smx;
+                    int place = -1;
+                    if (n < P.maxc) {
+                        place = n++;
+                    } else {
+                        // weakest candidate so far among 1..maxc-1 (first minimum wins)
+                        double ls = c_s - P.octave_cost * (log(P.min_pitch / c_f) * LOG2E_D);
+                        int li = lane;
+                        if (lane < 1 || lane >= P.maxc) { ls = 1e300; li = 1 << 20; }
+                        for (int off = 32; off > 0; off >>= 1) {
+                            const double os = __shfl_xor(ls, off, 64);
+                            const int oi = __shfl_xor(li, off, 64);
+                            if (os < ls || (os == ls && oi < li)) { ls = os; li = oi; }
+                        }
+                        double weakest = 2.0;
+                        if (ls < weakest) { weakest = ls; place = li; }
+                        if (smx - P.octave_cost * (log(P.min_pitch / fmx) * LOG2E_D) <= weakest) place = -1;
+                    }
+                    if (place >= 0 && lane == place) { c_f = fmx; c_s = smx; c_i = im; }
+                }
             }
         }
-        // second pass: maximise the sinc interpolation around every candidate
-        for (int q = 1; q < n; q++) {
-            const double fq = __shfl(c_f, q, 64);
-            const int iq = __shfl(c_i, q, 64);
-            double xmid;
-            double ymid = improve_maximum_wave(rr, ynx, iq + P.bix + 1, fq > 0.3 / P.dx ? 700 : 70, &xmid, lane);
-            xmid -= (double)(P.bix + 1);
-            if (ymid > 1.0) ymid = 1.0 / ymid;
-            if (lane == q) { c_f = 1.0 / P.dx / xmid; c_s = ymid; }
+        if (n > 1) {
+            // hand r[-bix..bix] and the candidate lags to k_pitch_refine
+            double *ro = rr_out + fidx * (int64_t)P.rr_len;
+            for (int k = lane; k < ynx; k += 64) ro[k] = rr[k];
+            // append to one of RF_LISTS lists: a single counter would serialise ~10^5 returning atomics in L2
+            const unsigned int list = (unsigned int)bid & (RF_LISTS - 1);
+            unsigned int pos = 0;
+            if (lane == 0) pos = atomicAdd(item_count + list * RF_CSTRIDE, (unsigned int)(n - 1));
+            pos = __shfl(pos, 0, 64);
+            if (lane >= 1 && lane < n) items[(size_t)list * list_cap + pos + lane - 1] = RefineItem{(long long)fidx, lane, c_i};
         }
     }
     if (lane < PI_MAXC) {
-        cand[fidx * 32 + lane] = lane < n ? c_f : 0.0;
-        cand[fidx * 32 + 16 + lane] = lane < n ? c_s : 0.0;
+        cand[fidx * 32 + lane] = 0.0;
+        cand[fidx * 32 + 16 + lane] = 0.0;
     }
     if (lane == 0) { ncand[fidx] = n; intensity[fidx] = inten; }
+}
+
+// ---------------------------------------------------------------------------
+// k_pitch_refine: Praat's second pass (NUMimproveMaximum, sinc depth 70/700) over the flat
+// list of candidates.  Sixteen lanes per candidate: the 144 autocorrelation values a
+// depth-70 interpolation can touch live in registers (9 per lane, fixed absolute indices),
+// the per-evaluation scalars (Brent state, sin) are shared by four candidates per wave, and
+// the 16-lane sums use DPP row operations (no LDS).  Trigonometry is evaluated with plain
+// polynomials: every argument is known to lie in (0, pi].
+// ---------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row; every lane of the row receives the same bits
+__device__ __forceinline__ double row_sum16(double v)
+{
+    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);    // row_half_mirror
+    v += dpp_f64<0x140>(v);    // row_mirror
+    return v;
+}
+// cos(h) and sin(h) for h in [0, pi/2] (Taylor about 0; truncation < 1e-19)
+__device__ __forceinline__ double cos_q(double h)
+{
+    const double z = h * h;
+    double p = 1.6117375710961184e-24;                 // 1/24!
+    p = fma(p, z, -8.8967913924505741e-22);            // -1/22!
+    p = fma(p, z, 4.1103176233121648e-19);
+    p = fma(p, z, -1.5619206968586225e-16);
+    p = fma(p, z, 4.7794773323873853e-14);
+    p = fma(p, z, -1.1470745597729725e-11);
+    p = fma(p, z, 2.0876756987868099e-09);
+    p = fma(p, z, -2.7557319223985888e-07);
+    p = fma(p, z, 2.4801587301587302e-05);
+    p = fma(p, z, -1.3888888888888889e-03);
+    p = fma(p, z, 4.1666666666666664e-02);
+    p = fma(p, z, -0.5);
+    return fma(p, z, 1.0);
+}
+__device__ __forceinline__ double sin_q(double h)
+{
+    const double z = h * h;
+    double p = -3.8681701706306841e-23;                // -1/23!
+    p = fma(p, z, 1.9572941063391263e-20);
+    p = fma(p, z, -8.2206352466243295e-18);
+    p = fma(p, z, 2.8114572543455206e-15);
+    p = fma(p, z, -7.6471637318198164e-13);
+    p = fma(p, z, 1.6059043836821613e-10);
+    p = fma(p, z, -2.5052108385441720e-08);
+    p = fma(p, z, 2.7557319223985893e-06);
+    p = fma(p, z, -1.9841269841269841e-04);
+    p = fma(p, z, 8.3333333333333332e-03);
+    p = fma(p, z, -1.6666666666666666e-01);
+    return fma(p * z, h, h);
+}
+__device__ __forceinline__ double sin_0pi(double a) { const double h = 0.5 * a; return 2.0 * sin_q(h) * cos_q(h); }
+__device__ __forceinline__ double one_plus_cos_0pi(double a) { const double c = cos_q(0.5 * a); return 2.0 * c * c; }
+__device__ __forceinline__ double rcp_f64(double a)
+{
+    double r = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-a, r, 1.0);
+    return fma(r, e, r);
+}
+
+// NUM_interpolate_sinc for a depth that stays inside the register window.
+// yv[m] = y[wbase + l16 + 16 m] (1-based y index); the caller guarantees 3 <= D and that
+// midleft is ixmid-1 or ixmid with wbase = ixmid - 71, so window rows m <= 3 lie left of x,
+// rows m >= 5 right of it and only row 4 straddles it.  Per lane the index distance k
+// changes by 16 from row to row: the (-1)^k sign is one value per side.  sin(pi (1 - t)) is
+// taken equal to sin(pi t) (Praat evaluates both; they differ by rounding only).
+__device__ __forceinline__ double sinc_term(double kd, double a0, double aa0, double daa, double hs, double yv, double dlim)
+{
+    const double a = fma(kd, PI_D, a0);
+    const double aa = fma(kd, daa, aa0);
+    const double w = hs * rcp_f64(a) * one_plus_cos_0pi(aa);
+    return (kd >= 0.0 && kd < dlim) ? yv * w : 0.0;
+}
+__device__ __forceinline__ double sinc_group_reg(const double (&yv)[9], int wbase, int ynx, double x, int maxDepth, int l16)
+{
+    const int midleft = (int)floor(x), midright = midleft + 1;
+    if (x == (double)midleft) {
+        double pick = 0.0;
+#pragma unroll
+        for (int m = 0; m < 9; m++) if (wbase + l16 + 16 * m == midleft) pick = yv[m];
+        return row_sum16(pick);
+    }
+    int D = maxDepth;
+    if (D > midright - 1) D = midright - 1;
+    if (D > ynx - midleft) D = ynx - midleft;
+    const double dlim = (double)D;
+    const int left = midright - D, right = midleft + D;
+    const double a_l = PI_D * (x - (double)midleft), a_r = PI_D * ((double)midright - x);
+    const double hs = 0.5 * sin_0pi(a_l);
+    const double rden_l = rcp_f64(x - (double)left + 1.0), rden_r = rcp_f64((double)right - x + 1.0);
+    const double aa_l = a_l * rden_l, daa_l = PI_D * rden_l;
+    const double aa_r = a_r * rden_r, daa_r = PI_D * rden_r;
+    const int kl0 = midleft - wbase - l16;            // k of row 0 on the left side (decreases by 16 per row)
+    const int kr0 = wbase + l16 - midright;           // k of row 0 on the right side (increases by 16 per row)
+    const double hs_l = (kl0 & 1) ? -hs : hs, hs_r = (kr0 & 1) ? -hs : hs;
+    const double kdl = (double)kl0, kdr = (double)kr0;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) acc += sinc_term(kdl - 16.0 * m, a_l, aa_l, daa_l, hs_l, yv[m], dlim);
+    {   // row 4 holds the lanes around x
+        const bool is_left = kl0 - 64 >= 0;
+        acc += sinc_term(is_left ? kdl - 64.0 : kdr + 64.0, is_left ? a_l : a_r, is_left ? aa_l : aa_r, is_left ? daa_l : daa_r,
+                         is_left ? hs_l : hs_r, yv[4], dlim);
+    }
+#pragma unroll
+    for (int m = 5; m < 9; m++) acc += sinc_term(kdr + 16.0 * m, a_r, aa_r, daa_r, hs_r, yv[m], dlim);
+    return row_sum16(acc);
+}
+
+// generic NUM_interpolate_sinc with y in global memory (depth 700, or windows near the array ends)
+__device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x, int maxDepth, int l16)
+{
+    const int midleft = (int)floor(x), midright = midleft + 1;
+    if (x > (double)ynx) return y[ynx - 1];
+    if (x < 1.0) return y[0];
+    if (x == (double)midleft) return y[midleft - 1];
+    if (maxDepth > midright - 1) maxDepth = midright - 1;
+    if (maxDepth > ynx - midleft) maxDepth = ynx - midleft;
+    if (maxDepth <= 0) return y[(int)floor(x + 0.5) - 1];
+    if (maxDepth == 1) return y[midleft - 1] + (x - (double)midleft) * (y[midright - 1] - y[midleft - 1]);
+    if (maxDepth == 2) {
+        const double yl = y[midleft - 1], yr = y[midright - 1];
+        const double dyl = 0.5 * (yr - y[midleft - 2]), dyr = 0.5 * (y[midright] - yl);
+        const double fil = x - (double)midleft, fir = (double)midright - x;
+        return yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2.0 * (yr - yl)));
+    }
+    const int left = midright - maxDepth, right = midleft + maxDepth;
+    const double a_l = PI_D * (x - (double)midleft), a_r = PI_D * ((double)midright - x);
+    const double hs_l = 0.5 * sin_0pi(a_l), hs_r = 0.5 * sin_0pi(a_r);
+    const double den_l = x - (double)left + 1.0, den_r = (double)right - x + 1.0;
+    const double aa_l = a_l / den_l, daa_l = PI_D / den_l;
+    const double aa_r = a_r / den_r, daa_r = PI_D / den_r;
+    double acc = 0.0;
+    for (int t = l16; t < 2 * maxDepth; t += 16) {
+        const bool is_left = t < maxDepth;
+        const int k = is_left ? t : t - maxDepth;
+        const double kd = (double)k;
+        const double a = fma(kd, PI_D, is_left ? a_l : a_r);
+        const double aa = fma(kd, is_left ? daa_l : daa_r, is_left ? aa_l : aa_r);
+        double hs = is_left ? hs_l : hs_r;
+        if (k & 1) hs = -hs;
+        const int ix = is_left ? midleft - k : midright + k;
+        acc += y[ix - 1] * (hs * rcp_f64(a) * one_plus_cos_0pi(aa));
+    }
+    return row_sum16(acc);
+}
+
+__global__ __launch_bounds__(256) void k_pitch_refine(PiParams P, const double *__restrict__ rr_in, const RefineItem *__restrict__ items,
+                                                     const unsigned int *__restrict__ item_count, unsigned int list_cap,
+                                                     double *__restrict__ cand)
+{
+    const int l16 = threadIdx.x & 15;
+    const unsigned int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const unsigned int list = gid & (RF_LISTS - 1);
+    const unsigned int group = gid / RF_LISTS;
+    const unsigned int n_groups = ((gridDim.x * blockDim.x) >> 4) / RF_LISTS;
+    const unsigned int count = item_count[list * RF_CSTRIDE];
+    items += (size_t)list * list_cap;
+    const int ynx = 2 * P.bix + 1;
+    const double golden = 1.0 - 0.6180339887498948482045868343656381177203;
+    const double sqrt_epsilon = 1.4901161193847656e-08;
+    const double tol = 1e-10;
+    for (unsigned int it = group; it < count; it += n_groups) {
+        const RefineItem item = items[it];
+        const double *y = rr_in + item.frame * (long long)P.rr_len;     // y[i-1] = Praat's y[i]
+        const int ixmid = item.imax + P.bix + 1;
+        // depth choice uses the first-pass (parabolic) frequency, as Praat does
+        const double r0 = y[ixmid - 1], rm = y[ixmid - 2], rp = y[ixmid];
+        const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
+        const double f1 = 1.0 / P.dx / ((double)item.imax + dr / d2r);
+        const int depth = f1 > 0.3 / P.dx ? 700 : 70;
+        double xres, yres;
+        if (ixmid <= 1) { xres = 1.0; yres = y[0]; }
+        else if (ixmid >= ynx) { xres = (double)ynx; yres = y[ynx - 1]; }
+        else {
+            // the register window serves midleft in {ixmid-1, ixmid}: needs depth <= 70 and D >= 3 for both
+            const bool fast = depth == 70 && ixmid - 1 >= 4 && ynx - ixmid >= 3;
+            const int wbase = ixmid - 71;
+            double yv[9];
+#pragma unroll
+            for (int m = 0; m < 9; m++) {
+                const int ix = wbase + l16 + 16 * m;
+                yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[ix - 1] : 0.0;
+            }
+            auto eval = [&](double xx) -> double {
+                return fast ? -sinc_group_reg(yv, wbase, ynx, xx, 70, l16) : -sinc_group_mem(y, ynx, xx, depth, l16);
+            };
+            double a = (double)(ixmid - 1), b = (double)(ixmid + 1);
+            double v = a + golden * (b - a);
+            double fv = eval(v);
+            double x = v, w = v, fx = fv, fw = fv;
+            for (int iter = 1; iter <= 60; iter++) {
+                const double range = b - a;
+                const double middle_range = (a + b) / 2.0;
+                const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.0;
+                if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) break;
+                double new_step = golden * (x < middle_range ? b - x : a - x);
+                if (fabs(x - w) >= tol_act) {
+                    double t = (x - w) * (fx - fv);
+                    double q = (x - v) * (fx - fw);
+                    double p = (x - v) * q - (x - w) * t;
+                    q = 2.0 * (q - t);
+                    if (q > 0.0) p = -p; else q = -q;
+                    if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
+                        new_step = p / q;
+                }
+                if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
+                const double t = x + new_step;
+                const double ft = eval(t);
+                if (ft <= fx) {
+                    if (t < x) b = x; else a = x;
+                    v = w; w = x; x = t;
+                    fv = fw; fw = fx; fx = ft;
+                } else {
+                    if (t < x) a = t; else b = t;
+                    if (ft <= fw || w == x) { v = w; w = t; fv = fw; fw = ft; }
+                    else if (ft <= fv || v == x || v == w) { v = t; fv = ft; }
+                }
+            }
+            xres = x; yres = -fx;
+        }
+        xres -= (double)(P.bix + 1);
+        if (yres > 1.0) yres = 1.0 / yres;
+        if (l16 == 0) {
+            cand[item.frame * 32 + item.slot] = 1.0 / P.dx / xres;
+            cand[item.frame * 32 + 16 + item.slot] = yres;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -350,17 +650,45 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
 // ---------------------------------------------------------------------------
 constexpr int BT_TILE = 1024;             // frames per back-tracking tile
 
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Local Viterbi terms of every (frame, candidate), computed by a flat elementwise pass so the
+// sequential path kernel only streams them: delta (Pitch_pathFinder's first loop) and log2(f),
+// with log2(f) = PATH_VOICELESS marking candidates the transition costs treat as voiceless.
+constexpr double PATH_VOICELESS = 1e300;
+__global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const double *__restrict__ cand, const double *__restrict__ intensity,
+                                                    long long n_frames, double2 *__restrict__ dl /* [frames][16] {delta, log2 f} */)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_frames * PI_MAXC) return;
+    const long long gi = e >> 4; const int jc = (int)(e & 15);
+    const double f = cand[gi * 32 + jc], st = cand[gi * 32 + 16 + jc];
+    const double inten = intensity[gi];
+    double uv = P.silence_thr <= 0.0 ? 0.0 : 2.0 - inten / (P.silence_thr / (1.0 + P.voicing_thr));
+    uv = P.voicing_thr + (uv > 0.0 ? uv : 0.0);
+    const bool voiceless_local = f == 0.0 || f > P.ceiling;
+    const bool voiceless_trans = f <= 0.0 || f >= P.ceiling;
+    const double delta = voiceless_local ? uv : st - P.octave_cost * (log(P.ceiling / f) * LOG2E_D);
+    dl[e] = make_double2(delta, voiceless_trans ? PATH_VOICELESS : log(f) * LOG2E_D);
+}
+
+// Lane ic (0..15) owns candidate ic of the current frame; the previous frame's running
+// delta and log2-frequency stay in those lanes' registers and are broadcast with v_readlane
+// (the loop over previous candidates is wave-uniform), so the recurrence touches neither LDS
+// nor a barrier.  The transition costs do not depend on the running delta and are formed
+// first; only "d1 - tc + d2 -> max" sits on the frame-to-frame dependency chain.
 __global__ __launch_bounds__(64) void k_pitch_path(
     const PiSlice *__restrict__ slices, PiParams P, const double *__restrict__ cand, const int *__restrict__ ncand,
-    const double *__restrict__ intensity, unsigned char *__restrict__ psi /* [frames][16] */,
+    const double2 *__restrict__ dl, unsigned char *__restrict__ psi /* [frames][16] */,
     double *__restrict__ f0, double *__restrict__ strength)
 {
-    __shared__ double t_f[PATH_TILE][PI_MAXC];      // candidate frequency
-    __shared__ double t_lf[PATH_TILE][PI_MAXC];     // log2(f)
-    __shared__ double t_d[PATH_TILE][PI_MAXC];      // local delta
+    __shared__ double2 t_dl[PATH_TILE][PI_MAXC];
     __shared__ int t_n[PATH_TILE];
-    __shared__ double p_f[PI_MAXC], p_lf[PI_MAXC], p_d[PI_MAXC];   // previous frame
-    __shared__ int p_n;
     __shared__ __attribute__((aligned(16))) unsigned char t_psi[BT_TILE][PI_MAXC];
     __shared__ unsigned char t_place[BT_TILE];
     __shared__ int s_place;
@@ -368,74 +696,56 @@ __global__ __launch_bounds__(64) void k_pitch_path(
     const int nF = s.n_frames;
     if (s.status != PCE_SLICE_OK || nF <= 0) return;
     const int lane = threadIdx.x;
-    const int ic2 = lane >> 2, g = lane & 3;
-    const double ceiling2 = P.ceiling;
+    const int ic = lane & 15;
     const double timeStepCorrection = 0.01 / P.dt;
     const double ojc = P.oj_cost * timeStepCorrection, vuc = P.vuv_cost * timeStepCorrection;
     const double *cs = cand + s.frame_off * 32;
     const int *ns = ncand + s.frame_off;
-    const double *is = intensity + s.frame_off;
+    const double2 *ds = dl + s.frame_off * PI_MAXC;
     unsigned char *ps = psi + s.frame_off * PI_MAXC;
 
+    double pd = 0.0, plf = 0.0;                      // previous frame, candidate `ic`
+    int pn = 0;
     for (int f0i = 0; f0i < nF; f0i += PATH_TILE) {
         const int tn = min(PATH_TILE, nF - f0i);
-        // stage the local deltas of tn frames x 16 candidates (parallel, off the recurrence)
-        for (int e = lane; e < tn * PI_MAXC; e += 64) {
-            const int fr = e >> 4, ic = e & 15;
-            const int64_t gi = f0i + fr;
-            const double f = cs[gi * 32 + ic], st = cs[gi * 32 + 16 + ic];
-            const double inten = is[gi];
-            double uv = P.silence_thr <= 0.0 ? 0.0 : 2.0 - inten / (P.silence_thr / (1.0 + P.voicing_thr));
-            uv = P.voicing_thr + (uv > 0.0 ? uv : 0.0);
-            const bool voiceless = f == 0.0 || f > ceiling2;
-            t_f[fr][ic] = f;
-            t_lf[fr][ic] = f > 0.0 ? log(f) * LOG2E_D : 0.0;
-            t_d[fr][ic] = voiceless ? uv : st - P.octave_cost * (log(P.ceiling / f) * LOG2E_D);
-            if (ic == 0) t_n[fr] = ns[gi];
-        }
         __syncthreads();
+        for (int e = lane; e < tn * PI_MAXC; e += 64) (&t_dl[0][0])[e] = ds[(int64_t)f0i * PI_MAXC + e];
+        if (lane < tn) t_n[lane] = ns[f0i + lane];
+        __syncthreads();
+        double2 cur = t_dl[0][ic];
+        int n2 = t_n[0];
         for (int fr = 0; fr < tn; fr++) {
+            const int nx = fr + 1 < tn ? fr + 1 : fr;
+            const double2 nxt = t_dl[nx][ic];                 // prefetch the next frame's operands
+            const int n2n = t_n[nx];
             const int gi = f0i + fr;
-            const int n2 = t_n[fr];
-            const double f2 = t_f[fr][ic2], lf2 = t_lf[fr][ic2], d2 = t_d[fr][ic2];
+            const double d2 = cur.x, lf2 = cur.y;
             double best = d2; int place = 0;
             if (gi > 0) {
                 best = -1e30;
-                const bool cur_vl = f2 <= 0.0 || f2 >= ceiling2;
-                const int pn = p_n;
-                for (int k = 0; k < 4; k++) {
-                    const int ic1 = g + 4 * k;
-                    if (ic1 < pn) {
-                        const double f1 = p_f[ic1];
-                        const bool prev_vl = f1 <= 0.0 || f1 >= ceiling2;
-                        double tc;
-                        if (cur_vl) tc = prev_vl ? 0.0 : vuc;
-                        else if (prev_vl) tc = vuc;
-                        else tc = ojc * fabs(p_lf[ic1] - lf2);
-                        const double value = p_d[ic1] - tc + d2;
-                        if (value > best) { best = value; place = ic1; }
-                    }
-                }
-                for (int off = 1; off <= 2; off <<= 1) {
-                    const double ob = __shfl_xor(best, off, 64);
-                    const int op = __shfl_xor(place, off, 64);
-                    if (ob > best || (ob == best && op < place)) { best = ob; place = op; }
+                const bool cur_vl = lf2 > 1e299;
+                for (int ic1 = 0; ic1 < pn; ic1 += 2) {
+                    const int ib = ic1 + 1 < pn ? ic1 + 1 : ic1;
+                    const double lfa = readlane_f64(plf, ic1), lfb = readlane_f64(plf, ib);
+                    const bool va = lfa > 1e299, vb = lfb > 1e299;
+                    const double tca = cur_vl ? (va ? 0.0 : vuc) : (va ? vuc : ojc * fabs(lfa - lf2));
+                    const double tcb = cur_vl ? (vb ? 0.0 : vuc) : (vb ? vuc : ojc * fabs(lfb - lf2));
+                    const double da = readlane_f64(pd, ic1), db = readlane_f64(pd, ib);
+                    const double vala = da - tca + d2, valb = db - tcb + d2;
+                    if (vala > best) { best = vala; place = ic1; }
+                    if (ib != ic1 && valb > best) { best = valb; place = ib; }
                 }
             }
-            __syncthreads();                      // every lane is done reading p_*
-            if (g == 0) {
-                p_d[ic2] = best; p_f[ic2] = f2; p_lf[ic2] = lf2;
-                ps[(int64_t)gi * PI_MAXC + ic2] = (unsigned char)place;
-                if (ic2 == 0) p_n = n2;
-            }
-            __syncthreads();
+            pd = best; plf = lf2; pn = n2;
+            if (lane < PI_MAXC) ps[(int64_t)gi * PI_MAXC + lane] = (unsigned char)place;
+            cur = nxt; n2 = n2n;
         }
     }
     // end of the most probable path: first maximum
-    if (lane == 0) {
-        int place = 0; double maximum = p_d[0];
-        for (int ic = 1; ic < p_n; ic++) if (p_d[ic] > maximum) { place = ic; maximum = p_d[ic]; }
-        s_place = place;
+    {
+        int place = 0; double maximum = readlane_f64(pd, 0);
+        for (int jc = 1; jc < pn; jc++) { const double v = readlane_f64(pd, jc); if (v > maximum) { place = jc; maximum = v; } }
+        if (lane == 0) s_place = place;
     }
     __threadfence_block();
     __syncthreads();
@@ -606,12 +916,19 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             P.oj_cost = p->octave_jump_cost; P.vuv_cost = p->voiced_unvoiced_cost;
             P.nsp = (int)pl.nsamp_period; P.hsp = (int)pl.halfnsamp_period; P.nw = (int)pl.nsamp_window; P.hw = (int)pl.halfnsamp_window;
             P.maxlag = (int)pl.maximum_lag; P.bix = (int)pl.brent_ixmax; P.maxc = (int)pl.max_candidates;
-            // xs is read up to index (nw-1) + (base + 63 + 192) with base < bix+1 rounded to 256
-            const int passes = (P.bix / 256) + 1;
-            P.xs_len = P.nw + passes * 256 + 2; P.xs_len += P.xs_len & 1;
+            int nfft = 8;
+            while ((double)nfft < (double)P.nw * 1.5) nfft *= 2;          // Praat's nsampFFT
+            P.nfft = nfft;
+            const int Mc = nfft / 2;
+            P.zlen = Mc + Mc / 8 + 2;
             P.rr_len = 2 * P.bix + 2;
-            const size_t lds = sizeof(double) * (size_t)(P.xs_len + P.rr_len) * PI_WPB;
+            const size_t lds = sizeof(double) * 4 * (size_t)P.zlen * PI_WPB;
             if (lds > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
+            std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
+            for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
+            for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
+            PCE_HIP(c, c->pi_tw.reserve(sizeof(double) * tw.size()));
+            PCE_HIP(c, hipMemcpyAsync(c->pi_tw.p, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice, c->stream));
             std::vector<double> window, windowR;
             make_window_tables(pl, window, windowR);
             PCE_HIP(c, c->pi_window.reserve(sizeof(double) * window.size()));
@@ -649,6 +966,10 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         PCE_HIP(c, c->pi_f0.reserve(sizeof(double) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_strength.reserve(sizeof(double) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_summary.reserve(sizeof(PiSummaryDev) * hs.size()));
+        PCE_HIP(c, c->pi_dl.reserve(sizeof(double) * 2 * PI_MAXC * (size_t)(total + 1)));
+        PCE_HIP(c, c->pi_rr.reserve(sizeof(double) * (size_t)P.rr_len * (size_t)(total + 1)));
+        PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)PI_WPB * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
+                                       + sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE));
         PCE_HIP(c, hipMemcpyAsync(c->pi_meta.p, hs.data(), sizeof(PiSlice) * hs.size(), hipMemcpyHostToDevice, c->stream));
         if (!work.empty())
             PCE_HIP(c, hipMemcpyAsync(c->pi_work.p, work.data(), sizeof(PiWork) * work.size(), hipMemcpyHostToDevice, c->stream));
@@ -670,19 +991,36 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         {
             int64_t nb = c->pi_n_work;
             nb = (nb + 7) & ~(int64_t)7;         // multiple of 8 so the XCD remap is a bijection; extra blocks exit
-            const size_t lds = sizeof(double) * (size_t)(P.xs_len + P.rr_len) * PI_WPB;
+            const size_t lds = sizeof(double) * 4 * (size_t)P.zlen * PI_WPB;
             if (lds > 64 * 1024)
                 PCE_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pitch_frames), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            KernelTimer t(c, PCE_K_PITCH_FRAMES);
-            hipLaunchKernelGGL(k_pitch_frames, dim3((unsigned)nb), dim3(64 * PI_WPB), lds, c->stream, c->d_pcm,
-                               c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,
-                               c->pi_window.as<double>(), c->pi_windowR.as<double>(), a_sum, a_hi, a_lo, stride,
-                               c->pi_cand.as<double>(), ncand, intensity);
+            const size_t cnt_bytes = sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE;
+            RefineItem *items = reinterpret_cast<RefineItem *>(c->pi_items.as<char>() + cnt_bytes);
+            unsigned int *item_count = c->pi_items.as<unsigned int>();
+            const unsigned int list_cap = (unsigned int)(div_up(nb, RF_LISTS) * PI_WPB * (PI_MAXC - 1));
+            PCE_HIP(c, hipMemsetAsync(item_count, 0, cnt_bytes, c->stream));
+            {
+                KernelTimer t(c, PCE_K_PITCH_FRAMES);
+                hipLaunchKernelGGL(k_pitch_frames, dim3((unsigned)nb), dim3(64 * PI_WPB), lds, c->stream, c->d_pcm,
+                                   c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,
+                                   c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
+                                   c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
+                                   c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap);
+            }
+            {
+                KernelTimer t(c, PCE_K_PITCH_REFINE);
+                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 8u;
+                hipLaunchKernelGGL(k_pitch_refine, dim3(blocks), dim3(256), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
+                                   list_cap, c->pi_cand.as<double>());
+            }
         }
         {
             KernelTimer t(c, PCE_K_PITCH_PATH);
+            const long long ne = total * PI_MAXC;
+            hipLaunchKernelGGL(k_pitch_delta, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, c->stream, P, c->pi_cand.as<double>(),
+                               intensity, (long long)total, c->pi_dl.as<double2>());
             hipLaunchKernelGGL(k_pitch_path, dim3((unsigned)n), dim3(64), 0, c->stream, c->pi_meta.as<PiSlice>(), P,
-                               c->pi_cand.as<double>(), ncand, intensity, c->pi_psi.as<unsigned char>(),
+                               c->pi_cand.as<double>(), ncand, c->pi_dl.as<double2>(), c->pi_psi.as<unsigned char>(),
                                c->pi_f0.as<double>(), c->pi_strength.as<double>());
         }
     }
