@@ -1,0 +1,94 @@
+"""CPU tests: the C-ABI library builds, loads and exports every symbol include/pce.h declares
+(no compute calls without a GPU), it refuses to run without a GPU, and the N>1 exchange step
+works over gloo with world_size 2."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_build_and_exports_match_header():
+    import __graft_entry__ as ge
+    ge.build()
+    from prosody_control_french_tts_amd import engine as E
+    lib = ctypes.CDLL(E.native_library_path())
+    header = open(os.path.join(ROOT, "include", "pce.h")).read()
+    declared = set(re.findall(r"\b(pce_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(E.EXPORTS), declared ^ set(E.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.pce_api_version.restype = ctypes.c_int
+    assert lib.pce_api_version() == 1
+    lib.pce_kernel_name.restype = ctypes.c_char_p
+    assert [lib.pce_kernel_name(i).decode() for i in range(len(E.KERNEL_IDS))] == E.KERNEL_IDS
+    # struct layouts the ctypes side assumes
+    assert ctypes.sizeof(E.Slice) == 32 and ctypes.sizeof(E.Energy) == 40
+    assert ctypes.sizeof(E.PitchParams) == 80 and ctypes.sizeof(E.PitchSummary) == 48
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import prosody_control_french_tts_amd as pkg
+    with pytest.raises(pkg.PceError, match="no HIP device|no CPU fallback"):
+        pkg.ProsodyEngine(0)
+
+
+def test_product_never_imports_oracle():
+    pkg_dir = os.path.join(ROOT, "prosody-control-french-tts_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "libpce_oracle" not in text, f
+
+
+def test_shard_ranges_cover_in_order():
+    from prosody_control_french_tts_amd import shard
+    for n in (0, 1, 7, 8, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [shard.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[3])
+import torch.distributed as dist
+from prosody_control_french_tts_amd import shard
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 11
+lo, hi = shard.shard_range(n, rank, world)
+full = np.arange(n * 7, dtype=np.float64).reshape(n, 7) * 0.5 - 3.0
+got = shard.allgather_records(full[lo:hi])
+assert got.shape == (n, 7) and np.array_equal(got, full), got
+empty = shard.allgather_records(np.zeros((0 if rank else 2, 3)))
+assert empty.shape == (2, 3)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_allgather_records_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = str(29600 + os.getpid() % 300)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -1,0 +1,162 @@
+"""GPU tests at the reference's own sample rate (44.1 kHz demo recordings) and through the
+drop-in step ``AudioPipeline.measure_prosody_and_build_ssml``."""
+import json
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from prosody_control_french_tts_amd import engine as E
+from prosody_control_french_tts_amd import hostrules as H
+from prosody_control_french_tts_amd import tagger as T
+from prosody_control_french_tts_amd import textgrid_io as TG
+from prosody_control_french_tts_amd.audio_pipeline import AudioPipeline
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def excerpts():
+    z = np.load(os.path.join(G, "demo_excerpts.npz"))
+    return int(z["rate"]), {k + ".wav": z[k] for k in z.files if k != "rate"}
+
+
+def test_g3_g4_goldens_through_the_gpu(engine, excerpts):
+    """R3 / R7 on the GPU path against the values the reference's own code produced."""
+    rate, clips = excerpts
+    names = sorted(clips)
+    engine.upload([clips[n] for n in names], rate)
+    cases = json.load(open(os.path.join(G, "rms_db.json")))
+    cl, b, e = [], [], []
+    for c in cases:
+        n = len(clips[c["file"]])
+        lo, hi = H.pydub_slice_frames(n, rate, c["start"] * 1000, c["end"] * 1000)
+        cl.append(names.index(c["file"])); b.append(lo); e.append(hi)
+    got = engine.energy(E.make_slices(cl, b, e))
+    for c, g in zip(cases, got):
+        if g["n"] == 0:
+            assert c["expected"] is None
+            continue
+        v = H.rms_db_from_wrapped(int(g["sum_sq_wrap16"]), int(g["n"]))
+        if isinstance(c["expected"], str):
+            assert str(v) == c["expected"]
+        else:
+            assert v == c["expected"]                       # bit-exact
+    gate = [c for c in json.load(open(os.path.join(G, "gate.json"))) if c["file"] in clips]
+    got = engine.energy(engine.whole_clip_slices(), 500)
+    for c in gate:
+        g = got[names.index(c["file"])]
+        rms, ratio, ok = H.gate_from_counts(int(g["sum_sq"]), int(g["n_loud"]), int(g["n"]))
+        assert ratio == c["silence_ratio"] and ok == c["ok"]
+        assert abs(float(rms) - c["rms_f32"]) <= 2e-6 * c["rms_f32"]
+
+
+def test_pitch_lufs_stft_at_44k1(engine, excerpts):
+    rate, clips = excerpts
+    names = sorted(clips)[:4]
+    engine.upload([clips[n] for n in names], rate)
+    sl = engine.whole_clip_slices()
+    res = engine.pitch(sl, E.PitchParams.praat(150.0, 600.0))
+    lu, st = engine.lufs(sl)
+    engine.stft_db_run(1024, 256)
+    for i, n in enumerate(names):
+        pcm = clips[n]
+        want = O.pitch_ac(pcm / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+        got = res["f0"][res["frame_offsets"][i]:res["frame_offsets"][i + 1]]
+        assert np.array_equal(got > 0, want > 0)
+        v = want > 0
+        assert v.sum() > 20 and np.max(np.abs(got[v] - want[v]) / want[v]) <= 1e-6
+        assert st[i] == 0 and abs(lu[i] - O.lufs_numpy(pcm.astype(float), rate)) <= 1e-6
+        sd = engine.stft_db_fetch(i); ref = O.stft_db(pcm.astype(np.float32) / 32768.0)
+        live = (ref > -79.9) & (sd > -79.9)
+        assert sd.shape == ref.shape and np.max(np.abs(sd[live] - ref[live])) <= 2e-2
+
+
+class OracleMeasurements(T.MeasurementSource):
+    """The reference closures (Code/audioPipeline.py:314-361) on the CPU oracle."""
+
+    def __init__(self, pcm, rate):
+        self.pcm, self.rate = pcm, rate
+
+    def median_pitch(self, segment, t0=0.0, t1=None):
+        return O.median_pitch(self.pcm[("nat", segment)], self.rate, t0, t1)
+
+    def lufs(self, kind, segment, t0=0.0, t1=None):
+        return O.get_lufs(self.pcm[(kind, segment)], self.rate, t0, t1, impl=O.lufs_numpy)
+
+    def duration(self, kind, segment):
+        return O.part_duration(len(self.pcm[(kind, segment)]), self.rate)
+
+    def part_duration(self, kind, segment, t0=0.0, t1=None):
+        return O.part_duration(len(self.pcm[(kind, segment)]), self.rate, t0, t1)
+
+
+def _write_wav(path, pcm, rate):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate); w.writeframes(pcm.astype("<i2").tobytes())
+
+
+def test_measure_and_build_ssml_step_matches_cpu_reference_path(engine, excerpts, tmp_path):
+    rate, clips = excerpts
+    rng = np.random.default_rng(11)
+    cfg = {"data_dir": "Data", "out_dir": "Out", "azure_voice_name": "fr-FR-HenriNeural", "whisper_device": "cuda:0",
+           "prosody_settings": {"baseline_window": 4, "pitch_semitones": 1.3, "pitch_lower_clip_factor": 0.7, "volume_pct": 10.0,
+                                "rate_percent": 10.0, "smoothing_alpha": 0.2, "max_jump_percent": 8, "end_punctuation_pause_ms": 500,
+                                "inter_syntagme_pause_factor": 1, "threshold_duration_before_slowing_down": 1.0, "slow_floor_per_sec": 2.0},
+           "steps_to_run": ["Measure & Build SSML"]}
+    voice = tmp_path / "Data" / "v1"
+    (voice / "audio").mkdir(parents=True); (voice / "WhisperTS_textgrid_files").mkdir()
+    raw = tmp_path / "Data" / "v1_raw" / "audio"; raw.mkdir(parents=True)
+    words = ["Bonjour", "le", "monde,", "voilà", "une", "phrase.", "Très", "longue", "ici?", "oui", "de", "la", "mer!"]
+    pcm, segs = {}, []
+    for name in sorted(clips)[:6]:
+        seg = name[:-4]
+        nat = clips[name]
+        syn = np.clip(np.roll(nat, 700).astype(np.int32) * 3 // 4, -32768, 32767).astype(np.int16)[: int(len(nat) * rng.uniform(0.8, 1.0))]
+        _write_wav(voice / "audio" / name, nat, rate); _write_wav(raw / name, syn, rate)
+        pcm[("nat", seg)], pcm[("syn", seg)] = nat, syn
+        t, ivs = 0.0, []
+        if rng.random() < 0.5:
+            ivs.append((0.0, 0.08, " ")); t = 0.08
+        while t < 1.05:
+            d = float(np.round(rng.uniform(0.09, 0.3), 3)); ivs.append((t, t + d, str(rng.choice(words)))); t += d
+            if rng.random() < 0.4:
+                d = float(np.round(rng.choice([0.06, 0.16, 0.25]), 3)); ivs.append((t, t + d, " ")); t += d
+        TG.write_textgrid(TG.TextGrid([TG.IntervalTier("words", ivs)], 0.0, t), voice / "WhisperTS_textgrid_files" / f"{seg}.TextGrid")
+        segs.append(T.SegmentInput(seg, TG.read_textgrid(voice / "WhisperTS_textgrid_files" / f"{seg}.TextGrid").tiers[0].intervals))
+    (raw / sorted(clips)[2]).write_bytes(b"not a wav")                  # CouldntDecodeError fallback path
+    del pcm[("syn", sorted(clips)[2][:-4])]
+
+    ap = AudioPipeline("v1", cfg, base=tmp_path, engine=engine)
+    res = ap.measure_prosody_and_build_ssml()
+
+    class Src(OracleMeasurements):
+        def _chk(self, kind, segment):
+            if (kind, segment) not in self.pcm:
+                raise T.CouldntDecodeError(segment)
+        def lufs(self, kind, segment, t0=0.0, t1=None):
+            self._chk(kind, segment); return super().lufs(kind, segment, t0, t1)
+        def duration(self, kind, segment):
+            self._chk(kind, segment); return super().duration(kind, segment)
+        def part_duration(self, kind, segment, t0=0.0, t1=None):
+            self._chk(kind, segment); return super().part_duration(kind, segment, t0, t1)
+
+    want = T.SsmlTagger(ap.settings, ap.azure_voice).run(segs, Src(pcm, rate))
+    # measurements: F0 medians within 1e-6 relative, LUFS within 1e-6 LU
+    for a, b in zip(res.segment_stats, want.segment_stats):
+        assert a["segment"] == b["segment"] and a["wc"] == b["wc"] and a["d_nat"] == b["d_nat"] and a["d_syn"] == b["d_syn"]
+        assert abs(a["p_nat"] - b["p_nat"]) <= 1e-6 * max(b["p_nat"], 1.0)
+        assert abs(a["l_nat"] - b["l_nat"]) <= 1e-6 and abs(a["l_syn"] - b["l_syn"]) <= 1e-6
+    for a, b in zip(res.rows, want.rows):
+        assert (a["segment"], a["syntagme"], a["pause"]) == (b["segment"], b["syntagme"], b["pause"])
+        for k in ("raw_pitch", "raw_volume", "raw_rate"):
+            assert abs(a[k] - b[k]) <= 1e-4
+    # the artefacts the reference step writes: identical text
+    for got_csv, df in ((ap.bdd_ssml_csv, want.bdd_ssml), (ap.bdd_syntagme_ssml_csv, want.bdd_syntagme_ssml),
+                        (ap.bdd_syntagme_synth_csv, want.bdd_syntagme_for_synth)):
+        p = tmp_path / ("want_" + got_csv.name)
+        df.to_csv(p, index=False)
+        assert got_csv.read_text(encoding="utf-8") == p.read_text(encoding="utf-8")

@@ -1,0 +1,139 @@
+"""Known-answer tests that pin the CPU oracle where no reference run is possible
+(third-party numerics: Praat, pyloudnorm, librosa -- "parity unpinned")."""
+import math
+
+import numpy as np
+import pytest
+import scipy.signal
+
+from oracle import oracle as O
+
+
+def harmonic(f, seconds=1.0, rate=16000, amp=0.5, harmonics=6):
+    t = np.arange(int(seconds * rate)) / rate
+    x = sum((1.0 / k) * np.sin(2 * np.pi * k * f * t) for k in range(1, harmonics + 1))
+    return np.round(amp * 32767 * x / np.max(np.abs(x))).astype(np.int16)
+
+
+@pytest.mark.parametrize("rate", [16000, 44100])
+@pytest.mark.parametrize("f", [160.0, 220.0, 333.3, 540.0])
+def test_pitch_of_periodic_signal(f, rate):
+    pcm = harmonic(f, 0.6, rate)
+    r = O.pitch_ac(pcm / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))
+    f0 = r["f0"]
+    assert (f0 > 0).all()
+    assert np.max(np.abs(f0 - f) / f) < 2e-3          # Hanning-window AC bias near the floor, < 0.2 %
+    assert np.all(r["strength"][f0 > 0] > 0.9)
+
+
+def test_pitch_frame_grid_matches_praat_formula():
+    # 10 s at 16 kHz, floor 150: dt 5 ms, window 20 ms -> 1997 frames centred in the sound
+    pl = O.pitch_plan(160000, 1 / 16000, 0.5 / 16000, O.praat_params(150.0, 600.0))
+    assert pl.n_frames == 1997 and abs(pl.dt - 0.005) < 1e-18
+    assert abs(pl.t1 - (5.0 - 0.5 * 1997 * 0.005 + 0.0025)) < 1e-12
+    assert (pl.nsamp_window, pl.nsamp_fft, pl.brent_ixmax, pl.maximum_lag, pl.nsamp_period) == (318, 512, 159, 108, 106)
+
+
+def test_pitch_silence_and_noise_are_unvoiced():
+    rate = 16000
+    z = np.zeros(rate)
+    assert not O.pitch_ac(z, 1 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"].any()
+    rng = np.random.default_rng(0)
+    n = rng.standard_normal(rate) * 0.05
+    f0 = O.pitch_ac(n, 1 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+    assert (f0 > 0).mean() < 0.1
+
+
+def test_pitch_too_short_raises_like_praat():
+    rate = 16000
+    with pytest.raises(O.PraatError):
+        O.pitch_ac(np.zeros(int(0.019 * rate)), 1 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))
+    O.pitch_ac(np.zeros(int(0.021 * rate)), 1 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))
+
+
+def test_octave_jump_is_resisted_by_path_finder():
+    # a frame-level octave error candidate exists (strong 2nd harmonic) but the path stays on f
+    rate, f = 16000, 200.0
+    t = np.arange(rate) / rate
+    x = 0.4 * np.sin(2 * np.pi * f * t) + 0.35 * np.sin(2 * np.pi * 2 * f * t)
+    f0 = O.pitch_ac(x, 1 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+    assert np.all(np.abs(f0 - f) < 2.0)
+
+
+def test_window_autocorrelation_is_closed_form():
+    p = O.praat_params(150.0, 600.0)
+    pl = O.pitch_plan(16000, 1 / 16000, 0.5 / 16000, p)
+    wr = O.window_autocorr(16000, 1 / 16000, 0.5 / 16000, p, pl.brent_ixmax + 1)
+    nw = pl.nsamp_window
+    w = 0.5 - 0.5 * np.cos(np.arange(1, nw + 1) * 2 * np.pi / (nw + 1))
+    direct = np.array([np.dot(w[:nw - k], w[k:]) for k in range(pl.brent_ixmax + 1)])
+    assert np.max(np.abs(wr - direct / direct[0])) < 1e-13
+
+
+@pytest.mark.parametrize("rate", [16000, 44100, 48000])
+def test_lufs_sine_closed_form(rate):
+    # stationary sine: LUFS = -0.691 + 10 log10(A^2/2 |H(f)|^2) with H the K-weighting cascade
+    f, amp = 997.0, 0.5
+    t = np.arange(5 * rate) / rate
+    x = amp * np.sin(2 * np.pi * f * t)
+    (b1, a1), (b2, a2) = O.kweight_coeffs(rate)
+    _, h1 = scipy.signal.freqz(b1, a1, worN=[2 * np.pi * f / rate])
+    _, h2 = scipy.signal.freqz(b2, a2, worN=[2 * np.pi * f / rate])
+    # get_lufs peak-normalises first: amplitude becomes 1.0
+    want = -0.691 + 10 * np.log10(0.5 * abs(h1[0] * h2[0]) ** 2)
+    assert abs(O.lufs_c(x * 32767, rate) - want) < 2e-3
+    assert abs(O.lufs_numpy(x * 32767, rate) - O.lufs_c(x * 32767, rate)) < 1e-9
+
+
+def test_lufs_c_equals_numpy_scipy_restatement():
+    rng = np.random.default_rng(5)
+    for n in (6400, 6401, 16000, 47999, 160000):
+        x = rng.standard_normal(n) * rng.uniform(10, 8000)
+        x[n // 3: n // 2] = 0.0
+        assert abs(O.lufs_c(x, 16000) - O.lufs_numpy(x, 16000)) < 1e-9
+    with pytest.raises(ValueError):
+        O.lufs_c(np.ones(6399), 16000)
+    assert O.lufs_c(np.zeros(8000), 16000) == -math.inf
+
+
+def test_lufs_gating_ignores_silence():
+    rng = np.random.default_rng(6)
+    loud = rng.standard_normal(16000 * 4) * 3000
+    padded = np.concatenate([loud, np.zeros(16000 * 6)])
+    # integrated loudness is gated: long digital silence must not pull the value down by more than the block edge effects
+    assert abs(O.lufs_c(padded / 1.0, 16000) - O.lufs_c(loud, 16000)) < 0.35
+
+
+def test_stft_db_properties():
+    rate = 16000
+    t = np.arange(rate) / rate
+    y = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    S = O.stft_db(y)
+    assert S.shape == (513, 1 + rate // 256) and S.dtype == np.float32
+    assert S.max() == 0.0 and S.min() >= -80.0
+    k = int(round(1000.0 / rate * 1024))
+    assert np.all(np.argmax(S[:, 5:-5], axis=0) == k)
+    # Parseval on one interior frame of the underlying transform (periodic Hann, no padding involved)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1024)
+    fr = y[2048 - 512:2048 + 512] * w
+    X = np.fft.rfft(fr)
+    e_f = (np.abs(X[0]) ** 2 + 2 * np.sum(np.abs(X[1:-1]) ** 2) + np.abs(X[-1]) ** 2) / 1024
+    assert abs(e_f - np.sum(fr.astype(np.float64) ** 2)) < 1e-3 * e_f
+
+
+def test_pydub_and_praat_slicing_rules():
+    n, rate = 44100 * 3 + 17, 44100
+    assert O.pydub_len_ms(n, rate) == round(1000 * n / rate)
+    b, k, pad = O.pydub_slice(n, rate, 500, 1500)
+    assert (b, k, pad) == (int(500 * 44.1), int(1500 * 44.1) - int(500 * 44.1), 0)
+    # slice running to len(): the last partial millisecond is padded with silence
+    L = O.pydub_len_ms(n, rate)                       # 3000.385 ms rounds DOWN: the tail of the file is unreachable
+    b, k, pad = O.pydub_slice(n, rate, L - 10, L + 50)
+    assert b + k == int(L * 44.1) < n and pad == 0
+    n2 = 44100 * 3 + 30                               # 3000.68 ms rounds UP: pydub pads the missing frames with silence
+    L2 = O.pydub_len_ms(n2, rate)
+    b, k, pad = O.pydub_slice(n2, rate, L2 - 10, None)
+    assert L2 == 3001 and b + k == n2 and pad == int(3001 * 44.1) - n2 == 14
+    ix1, ix2, x1 = O.praat_extract_part(n, rate, 0.25, 0.75)
+    assert ix1 == 1 + math.ceil((0.25 - 0.5 / rate) * rate) and ix2 == 1 + math.floor((0.75 - 0.5 / rate) * rate)
+    assert abs(x1 - (0.5 / rate + (ix1 - 1) / rate)) < 1e-15
