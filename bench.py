@@ -36,7 +36,7 @@ def algorithmic_bytes(kernel: str, n_clips: int, n_samples: int, n_pitch_frames:
         "k_lufs_pass1": pcm, "k_lufs_pass2": pcm,
         "k_lufs_scan": 0.0, "k_lufs_gate": 0.0,
         "k_pitch_frames": pcm + 8.0 * n_pitch_frames * n_clips,
-        "k_pitch_refine": 0.0,
+        "k_pitch_refine": 0.0, "k_pitch_delta": 0.0,
         "k_pitch_path": 8.0 * n_pitch_frames * n_clips, "k_pitch_median": 8.0 * n_pitch_frames * n_clips,
         "k_stft_max": pcm,
         "k_stft_db": pcm + 513 * 4.0 * n_stft_frames * n_clips,

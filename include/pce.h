@@ -163,7 +163,7 @@ int pce_stft_db_device(pce_ctx *ctx, const void **d_ptr, int64_t *bytes);
 enum pce_kernel_id {
     PCE_K_ENERGY = 0,
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
-    PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN,
+    PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
     PCE_K_STFT_MAX, PCE_K_STFT_DB,
     PCE_K_COUNT
 };

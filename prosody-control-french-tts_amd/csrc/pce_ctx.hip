@@ -90,7 +90,7 @@ void pce_destroy(pce_ctx *c)
                       &c->lu_meta, &c->lu_chunks, &c->lu_blocks, &c->lu_pow, &c->lu_state_end, &c->lu_state_init,
                       &c->lu_energy, &c->lu_zbuf, &c->lu_out, &c->lu_en_work, &c->lu_en_acc,
                       &c->pi_meta, &c->pi_window, &c->pi_windowR, &c->pi_work, &c->pi_cand, &c->pi_gpeak,
-                      &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc, &c->pi_rr, &c->pi_items, &c->pi_tw, &c->pi_dl,
+                      &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc, &c->pi_rr, &c->pi_items, &c->pi_tw, &c->pi_dl, &c->pi_runs, &c->pi_fslice,
                       &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work};
     for (auto b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -183,7 +183,7 @@ const char *pce_kernel_name(int id)
 {
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-        "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median",
+        "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
         "k_stft_max", "k_stft_db"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }

@@ -648,7 +648,11 @@ __global__ __launch_bounds__(256) void k_pitch_refine(PiParams P, const double *
 // ---------------------------------------------------------------------------
 // Pitch_pathFinder: one wavefront per slice
 // ---------------------------------------------------------------------------
-constexpr int BT_TILE = 1024;             // frames per back-tracking tile
+constexpr int BT_TILE = 256;              // frames per back-tracking tile
+constexpr int RUN_LISTS = 64;             // independent run lists (see RF_LISTS)
+constexpr double PATH_VOICELESS = 1e300;
+
+struct PathRun { long long frame; int slice; int pad; };
 
 __device__ __forceinline__ double readlane_f64(double v, int src)
 {
@@ -657,12 +661,19 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// Local Viterbi terms of every (frame, candidate), computed by a flat elementwise pass so the
-// sequential path kernel only streams them: delta (Pitch_pathFinder's first loop) and log2(f),
-// with log2(f) = PATH_VOICELESS marking candidates the transition costs treat as voiceless.
-constexpr double PATH_VOICELESS = 1e300;
-__global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const double *__restrict__ cand, const double *__restrict__ intensity,
-                                                    long long n_frames, double2 *__restrict__ dl /* [frames][16] {delta, log2 f} */)
+// Elementwise pre-pass of Pitch_pathFinder over every (frame, candidate):
+//   dl = {local delta (the finder's first loop), log2 f or PATH_VOICELESS}
+// plus the bookkeeping that makes the Viterbi parallel: a frame with a single candidate (the
+// voiceless one) is a *cut*: every path passes through it, and the additive constant it
+// carries cannot change any later arg-max.  So the recurrence only has to run over maximal
+// runs of multi-candidate frames, all runs independently.  Cut frames get their result
+// (f0 = 0) here; run starts are appended to RUN_LISTS lists.
+__global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const PiSlice *__restrict__ slices, const int *__restrict__ frame_slice,
+                                                    const double *__restrict__ cand, const int *__restrict__ ncand,
+                                                    const double *__restrict__ intensity, long long n_frames,
+                                                    double2 *__restrict__ dl /* [frames][16] */, double *__restrict__ f0,
+                                                    double *__restrict__ strength, PathRun *__restrict__ runs,
+                                                    unsigned int *__restrict__ run_count, unsigned int run_cap)
 {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_frames * PI_MAXC) return;
@@ -675,101 +686,124 @@ __global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const double *_
     const bool voiceless_trans = f <= 0.0 || f >= P.ceiling;
     const double delta = voiceless_local ? uv : st - P.octave_cost * (log(P.ceiling / f) * LOG2E_D);
     dl[e] = make_double2(delta, voiceless_trans ? PATH_VOICELESS : log(f) * LOG2E_D);
+    if (jc == 0) {
+        const int n = ncand[gi];
+        if (n <= 1) { f0[gi] = 0.0; strength[gi] = 0.0; }
+        else {
+            const int sl = frame_slice[gi];
+            const long long li = gi - slices[sl].frame_off;
+            if (li == 0 || ncand[gi - 1] <= 1) {
+                const unsigned int list = (unsigned int)(gi >> 2) & (RUN_LISTS - 1);
+                const unsigned int pos = atomicAdd(run_count + list * RF_CSTRIDE, 1u);
+                runs[(size_t)list * run_cap + pos] = PathRun{gi, sl, 0};
+            }
+        }
+    }
 }
 
-// Lane ic (0..15) owns candidate ic of the current frame; the previous frame's running
-// delta and log2-frequency stay in those lanes' registers and are broadcast with v_readlane
-// (the loop over previous candidates is wave-uniform), so the recurrence touches neither LDS
-// nor a barrier.  The transition costs do not depend on the running delta and are formed
-// first; only "d1 - tc + d2 -> max" sits on the frame-to-frame dependency chain.
+// Viterbi over one run of multi-candidate frames per wavefront.  Lane ic (0..15) owns
+// candidate ic of the current frame; the previous frame's running delta and log2-frequency
+// stay in those lanes' registers and are broadcast with v_readlane (the loop over previous
+// candidates is wave-uniform), so the recurrence touches neither LDS nor a barrier.
 __global__ __launch_bounds__(64) void k_pitch_path(
     const PiSlice *__restrict__ slices, PiParams P, const double *__restrict__ cand, const int *__restrict__ ncand,
-    const double2 *__restrict__ dl, unsigned char *__restrict__ psi /* [frames][16] */,
-    double *__restrict__ f0, double *__restrict__ strength)
+    const double2 *__restrict__ dl, const PathRun *__restrict__ runs, const unsigned int *__restrict__ run_count, unsigned int run_cap,
+    unsigned char *__restrict__ psi /* [frames][16] */, double *__restrict__ f0, double *__restrict__ strength)
 {
     __shared__ double2 t_dl[PATH_TILE][PI_MAXC];
     __shared__ int t_n[PATH_TILE];
     __shared__ __attribute__((aligned(16))) unsigned char t_psi[BT_TILE][PI_MAXC];
     __shared__ unsigned char t_place[BT_TILE];
     __shared__ int s_place;
-    const PiSlice s = slices[blockIdx.x];
-    const int nF = s.n_frames;
-    if (s.status != PCE_SLICE_OK || nF <= 0) return;
     const int lane = threadIdx.x;
     const int ic = lane & 15;
     const double timeStepCorrection = 0.01 / P.dt;
     const double ojc = P.oj_cost * timeStepCorrection, vuc = P.vuv_cost * timeStepCorrection;
-    const double *cs = cand + s.frame_off * 32;
-    const int *ns = ncand + s.frame_off;
-    const double2 *ds = dl + s.frame_off * PI_MAXC;
-    unsigned char *ps = psi + s.frame_off * PI_MAXC;
-
-    double pd = 0.0, plf = 0.0;                      // previous frame, candidate `ic`
-    int pn = 0;
-    for (int f0i = 0; f0i < nF; f0i += PATH_TILE) {
-        const int tn = min(PATH_TILE, nF - f0i);
-        __syncthreads();
-        for (int e = lane; e < tn * PI_MAXC; e += 64) (&t_dl[0][0])[e] = ds[(int64_t)f0i * PI_MAXC + e];
-        if (lane < tn) t_n[lane] = ns[f0i + lane];
-        __syncthreads();
-        double2 cur = t_dl[0][ic];
-        int n2 = t_n[0];
-        for (int fr = 0; fr < tn; fr++) {
-            const int nx = fr + 1 < tn ? fr + 1 : fr;
-            const double2 nxt = t_dl[nx][ic];                 // prefetch the next frame's operands
-            const int n2n = t_n[nx];
-            const int gi = f0i + fr;
-            const double d2 = cur.x, lf2 = cur.y;
-            double best = d2; int place = 0;
-            if (gi > 0) {
-                best = -1e30;
-                const bool cur_vl = lf2 > 1e299;
-                for (int ic1 = 0; ic1 < pn; ic1 += 2) {
-                    const int ib = ic1 + 1 < pn ? ic1 + 1 : ic1;
-                    const double lfa = readlane_f64(plf, ic1), lfb = readlane_f64(plf, ib);
-                    const bool va = lfa > 1e299, vb = lfb > 1e299;
-                    const double tca = cur_vl ? (va ? 0.0 : vuc) : (va ? vuc : ojc * fabs(lfa - lf2));
-                    const double tcb = cur_vl ? (vb ? 0.0 : vuc) : (vb ? vuc : ojc * fabs(lfb - lf2));
-                    const double da = readlane_f64(pd, ic1), db = readlane_f64(pd, ib);
-                    const double vala = da - tca + d2, valb = db - tcb + d2;
-                    if (vala > best) { best = vala; place = ic1; }
-                    if (ib != ic1 && valb > best) { best = valb; place = ib; }
+    const unsigned int list = blockIdx.x & (RUN_LISTS - 1);
+    const unsigned int count = run_count[list * RF_CSTRIDE];
+    for (unsigned int r = blockIdx.x / RUN_LISTS; r < count; r += gridDim.x / RUN_LISTS) {
+        const PathRun run = runs[(size_t)list * run_cap + r];
+        const PiSlice s = slices[run.slice];
+        const long long gs = run.frame, gend = s.frame_off + s.n_frames;     // run start, slice end (global frame indices)
+        double pd = 0.0, plf = PATH_VOICELESS;           // previous frame, candidate `ic`
+        int pn = 0;
+        if (gs > s.frame_off) {                          // the cut frame before the run: its only candidate is voiceless
+            pd = dl[(gs - 1) * PI_MAXC].x; plf = PATH_VOICELESS; pn = 1;
+        }
+        long long ge = gs;                               // one past the last frame of the run
+        bool open = true;
+        while (open) {
+            const int tn = (int)min((long long)PATH_TILE, gend - ge);
+            __syncthreads();
+            for (int e = lane; e < tn * PI_MAXC; e += 64) (&t_dl[0][0])[e] = dl[ge * PI_MAXC + e];
+            if (lane < tn) t_n[lane] = ncand[ge + lane];
+            __syncthreads();
+            int fr = 0;
+            double2 cur = t_dl[0][ic];
+            int n2 = t_n[0];
+            unsigned char *pp = psi + ge * PI_MAXC + ic;
+            for (; fr < tn; fr++) {
+                if (n2 <= 1) { open = false; break; }
+                const int nx = fr + 1 < tn ? fr + 1 : fr;
+                const double2 nxt = t_dl[nx][ic];             // prefetch the next frame's operands
+                const int n2n = t_n[nx];
+                const double d2 = cur.x, lf2 = cur.y;
+                double best = d2; int place = 0;
+                if (pn > 0) {
+                    best = -1e30;
+                    const bool cur_vl = lf2 > 1e299;
+                    for (int ic1 = 0; ic1 < pn; ic1++) {
+                        const double lf1 = readlane_f64(plf, ic1), d1 = readlane_f64(pd, ic1);
+                        const bool pv = lf1 > 1e299;
+                        const double tc = (cur_vl != pv) ? vuc : (cur_vl ? 0.0 : ojc * fabs(lf1 - lf2));
+                        const double value = d1 - tc + d2;
+                        const bool better = value > best;
+                        best = better ? value : best; place = better ? ic1 : place;
+                    }
                 }
+                pd = best; plf = lf2; pn = n2;
+                pp[fr * PI_MAXC] = (unsigned char)place;      // lanes 16..63 rewrite the same bytes
+                cur = nxt; n2 = n2n;
             }
-            pd = best; plf = lf2; pn = n2;
-            if (lane < PI_MAXC) ps[(int64_t)gi * PI_MAXC + lane] = (unsigned char)place;
-            cur = nxt; n2 = n2n;
+            ge += fr;
+            if (ge >= gend) open = false;
         }
-    }
-    // end of the most probable path: first maximum
-    {
-        int place = 0; double maximum = readlane_f64(pd, 0);
-        for (int jc = 1; jc < pn; jc++) { const double v = readlane_f64(pd, jc); if (v > maximum) { place = jc; maximum = v; } }
-        if (lane == 0) s_place = place;
-    }
-    __threadfence_block();
-    __syncthreads();
-    // back-track through LDS tiles, last tile first
-    for (int hi = nF; hi > 0;) {
-        const int lo = max(0, hi - BT_TILE);
-        const int cnt = hi - lo;
-        for (int e = lane; e < cnt; e += 64)
-            *reinterpret_cast<uint4 *>(&t_psi[e][0]) = *reinterpret_cast<const uint4 *>(ps + (int64_t)(lo + e) * PI_MAXC);
-        __syncthreads();
-        if (lane == 0) {
-            int place = s_place;
-            for (int i = cnt - 1; i >= 0; i--) { t_place[i] = (unsigned char)place; place = t_psi[i][place]; }
-            s_place = place;
+        // choose the end of the path inside the run
+        {
+            int place = 0; double maximum = -1e30;
+            const bool cut_follows = ge < gend;          // frame `ge` is a cut frame (single voiceless candidate)
+            const double dn = cut_follows ? dl[ge * PI_MAXC].x : 0.0;
+            for (int jc = 0; jc < pn; jc++) {
+                const double v = readlane_f64(pd, jc), lf = readlane_f64(plf, jc);
+                const double value = cut_follows ? (v - ((lf > 1e299) ? 0.0 : vuc) + dn) : v;
+                if (jc == 0 || value > maximum) { place = jc; maximum = value; }
+            }
+            if (lane == 0) s_place = place;
         }
+        __threadfence_block();
         __syncthreads();
-        for (int e = lane; e < cnt; e += 64) {
-            const int64_t gi = lo + e;
-            const int pl = t_place[e];
-            f0[s.frame_off + gi] = cs[gi * 32 + pl];
-            strength[s.frame_off + gi] = cs[gi * 32 + 16 + pl];
+        // back-track through LDS tiles, last tile first
+        for (long long hi = ge; hi > gs;) {
+            const long long lo = max(gs, hi - BT_TILE);
+            const int cnt = (int)(hi - lo);
+            for (int e = lane; e < cnt; e += 64)
+                *reinterpret_cast<uint4 *>(&t_psi[e][0]) = *reinterpret_cast<const uint4 *>(psi + (lo + e) * PI_MAXC);
+            __syncthreads();
+            if (lane == 0) {
+                int place = s_place;
+                for (int i = cnt - 1; i >= 0; i--) { t_place[i] = (unsigned char)place; place = t_psi[i][place]; }
+                s_place = place;
+            }
+            __syncthreads();
+            for (int e = lane; e < cnt; e += 64) {
+                const long long gi = lo + e;
+                const int pl = t_place[e];
+                f0[gi] = cand[gi * 32 + pl];
+                strength[gi] = cand[gi * 32 + 16 + pl];
+            }
+            __syncthreads();
+            hi = lo;
         }
-        __syncthreads();
-        hi = lo;
     }
 }
 
@@ -966,6 +1000,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         PCE_HIP(c, c->pi_f0.reserve(sizeof(double) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_strength.reserve(sizeof(double) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_summary.reserve(sizeof(PiSummaryDev) * hs.size()));
+        PCE_HIP(c, c->pi_runs.reserve(sizeof(unsigned int) * RUN_LISTS * RF_CSTRIDE + sizeof(PathRun) * (size_t)RUN_LISTS * (size_t)(total / RUN_LISTS + 64)));
+        PCE_HIP(c, c->pi_fslice.reserve(sizeof(int) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_dl.reserve(sizeof(double) * 2 * PI_MAXC * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_rr.reserve(sizeof(double) * (size_t)P.rr_len * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)PI_WPB * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
@@ -973,6 +1009,10 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         PCE_HIP(c, hipMemcpyAsync(c->pi_meta.p, hs.data(), sizeof(PiSlice) * hs.size(), hipMemcpyHostToDevice, c->stream));
         if (!work.empty())
             PCE_HIP(c, hipMemcpyAsync(c->pi_work.p, work.data(), sizeof(PiWork) * work.size(), hipMemcpyHostToDevice, c->stream));
+        std::vector<int> fslice((size_t)total + 1, 0);
+        for (int32_t i = 0; i < n; i++)
+            for (int64_t f = c->pi_frame_off[(size_t)i]; f < c->pi_frame_off[(size_t)i + 1]; f++) fslice[(size_t)f] = i;
+        PCE_HIP(c, hipMemcpyAsync(c->pi_fslice.p, fslice.data(), sizeof(int) * fslice.size(), hipMemcpyHostToDevice, c->stream));
         PCE_HIP(c, hipStreamSynchronize(c->stream));
         rc = pce_energy_plan(c, slices, n, c->pi_peakwork, c->pi_acc, &c->pi_n_energy_work);
         if (rc) return rc;
@@ -1015,13 +1055,25 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             }
         }
         {
-            KernelTimer t(c, PCE_K_PITCH_PATH);
+            const size_t rc_bytes = sizeof(unsigned int) * RUN_LISTS * RF_CSTRIDE;
+            unsigned int *run_count = c->pi_runs.as<unsigned int>();
+            PathRun *runs = reinterpret_cast<PathRun *>(c->pi_runs.as<char>() + rc_bytes);
+            const unsigned int run_cap = (unsigned int)(total / RUN_LISTS + 64);
+            PCE_HIP(c, hipMemsetAsync(run_count, 0, rc_bytes, c->stream));
             const long long ne = total * PI_MAXC;
-            hipLaunchKernelGGL(k_pitch_delta, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, c->stream, P, c->pi_cand.as<double>(),
-                               intensity, (long long)total, c->pi_dl.as<double2>());
-            hipLaunchKernelGGL(k_pitch_path, dim3((unsigned)n), dim3(64), 0, c->stream, c->pi_meta.as<PiSlice>(), P,
-                               c->pi_cand.as<double>(), ncand, c->pi_dl.as<double2>(), c->pi_psi.as<unsigned char>(),
-                               c->pi_f0.as<double>(), c->pi_strength.as<double>());
+            {
+                KernelTimer t(c, PCE_K_PITCH_DELTA);
+                hipLaunchKernelGGL(k_pitch_delta, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, c->stream, P, c->pi_meta.as<PiSlice>(),
+                                   c->pi_fslice.as<int>(), c->pi_cand.as<double>(), ncand, intensity, (long long)total,
+                                   c->pi_dl.as<double2>(), c->pi_f0.as<double>(), c->pi_strength.as<double>(), runs, run_count, run_cap);
+            }
+            {
+                KernelTimer t(c, PCE_K_PITCH_PATH);
+                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 16u;     // multiple of RUN_LISTS
+                hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, c->stream, c->pi_meta.as<PiSlice>(), P,
+                                   c->pi_cand.as<double>(), ncand, c->pi_dl.as<double2>(), runs, run_count, run_cap,
+                                   c->pi_psi.as<unsigned char>(), c->pi_f0.as<double>(), c->pi_strength.as<double>());
+            }
         }
     }
     if (n > 0) {
