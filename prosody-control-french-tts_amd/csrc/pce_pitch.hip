@@ -27,6 +27,7 @@
 // sample plus 8 B of F0 per frame.
 #include "pce_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work_buf, DevBuf &out_buf, int64_t *n_work);
 int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
     const long long *acc_sum, const int *acc_hi, const int *acc_lo, size_t acc_stride,
     double *__restrict__ cand /* [frames][32]: 16 freq, 16 strength */, int *__restrict__ ncand, double *__restrict__ intensity,
     double *__restrict__ rr_out /* [frames][rr_len] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
-    unsigned int list_cap)
+    unsigned int list_cap, int dbg)
 {
     extern __shared__ double lds[];
     // XCD-aware remap: consecutive work items (overlapping windows of one slice) go to one XCD's L2
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
     if (localPeak != 0.0) {
         wave_sync();
         // forward transform of the packed frame
-        double2 *Z = fft_wave(bufA, bufB, M, twM, lane);
+        double2 *Z = (dbg & 1) ? bufA : fft_wave(bufA, bufB, M, twM, lane);
         double2 *W = (Z == bufA) ? bufB : bufA;
         // power spectrum of the real frame, re-tangled for the second (inverse) transform
         for (int k = lane; k <= (M >> 1); k += 64) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
             if (k != 0 && k != M - k) W[ZP(M - k)] = make_double2(e + d * sn, -(d * c));
         }
         wave_sync();
-        double2 *Y = fft_wave(W, Z, M, twM, lane);
+        double2 *Y = (dbg & 1) ? W : fft_wave(W, Z, M, twM, lane);
         rr = reinterpret_cast<double *>((Y == bufA) ? bufB : bufA);       // the free buffer holds r[-bix..bix]
         const double ac0 = Y[0].x;
         for (int k = lane + 1; k <= P.bix; k += 64) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
                 }
             }
         }
-        if (n > 1) {
+        if (n > 1 && !(dbg & 2)) {
             // hand r[-bix..bix] and the candidate lags to k_pitch_refine
             double *ro = rr_out + fidx * (int64_t)P.rr_len;
             for (int k = lane; k < ynx; k += 64) ro[k] = rr[k];
@@ -1045,7 +1046,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                                    c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,
                                    c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
                                    c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
-                                   c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap);
+                                   c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap,
+                                   getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0);
             }
             {
                 KernelTimer t(c, PCE_K_PITCH_REFINE);
