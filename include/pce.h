@@ -157,6 +157,34 @@ int pce_stft_db_fetch(pce_ctx *ctx, int32_t clip, float *out);
 /* device pointer + byte size of the resident result (all clips, concatenated) */
 int pce_stft_db_device(pce_ctx *ctx, const void **d_ptr, int64_t *bytes);
 
+/* ---- R8: log-mel spectrogram + Whisper audio encoder --------------------
+ * Replaces the device work of whisper_timestamped.transcribe before decoding
+ * (Code/Aligners/use_whisper_timestamped.py:139,150-163; openai-whisper==20240930):
+ * whisper.log_mel_spectrogram on the 30 s window starting at sample 0 of every
+ * uploaded clip (16 kHz; shorter clips are zero padded, as whisper.pad_or_trim
+ * does), then AudioEncoder.forward.  Matmuls run in bf16 on MFMA with fp32
+ * accumulation; the residual stream is fp32.
+ *
+ * Weight blob (float32, this order; Linear/Conv weights in PyTorch layout):
+ *   conv1.weight[d][n_mels][3] conv1.bias[d] conv2.weight[d][d][3] conv2.bias[d]
+ *   per layer: attn_ln.w[d] attn_ln.b[d] query.w[d][d] query.b[d] key.w[d][d]
+ *              value.w[d][d] value.b[d] out.w[d][d] out.b[d] mlp_ln.w[d] mlp_ln.b[d]
+ *              mlp.0.w[4d][d] mlp.0.b[4d] mlp.2.w[d][4d] mlp.2.b[d]
+ *   ln_post.w[d] ln_post.b[d]
+ * The sinusoidal positional embedding is generated inside the library. */
+typedef struct pce_whisper_dims {
+    int32_t n_mels;    /* 80 (128 for large-v3)          */
+    int32_t n_ctx;     /* 1500                            */
+    int32_t n_state;   /* d: 384/512/768/1024/1280        */
+    int32_t n_head;    /* d / 64                          */
+    int32_t n_layer;
+} pce_whisper_dims;
+int pce_logmel_run(pce_ctx *ctx, int32_t n_mels);
+int pce_logmel_fetch(pce_ctx *ctx, int32_t clip, float *out /* [n_mels][3000] */);
+int pce_whisper_load(pce_ctx *ctx, const pce_whisper_dims *dims, const float *weights, int64_t n_floats);
+int pce_whisper_encode_run(pce_ctx *ctx);
+int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
+
 /* ---- measurement -------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; pce_profile_get returns the accumulated device time. */
@@ -164,7 +192,7 @@ enum pce_kernel_id {
     PCE_K_ENERGY = 0,
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
-    PCE_K_STFT_MAX, PCE_K_STFT_DB,
+    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC,
     PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);

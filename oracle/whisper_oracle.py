@@ -1,0 +1,89 @@
+"""oracle/whisper_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+torch (CPU, float32) restatement of openai-whisper==20240930's ``log_mel_spectrogram`` and
+``AudioEncoder.forward`` (whisper/audio.py, whisper/model.py), the device work behind
+``whisper_timestamped.transcribe`` (Code/Aligners/use_whisper_timestamped.py:139,150-163).
+**Parity unpinned**: openai-whisper is a third-party dependency absent from /root/reference and
+not installed here, and no checkpoint is available offline; the architecture is restated from
+its published definition and exercised with fixed-seed synthetic weights.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+N_FFT, HOP, N_SAMPLES, N_FRAMES = 400, 160, 480000, 3000
+
+
+def mel_filters(n_mels=80, sr=16000, n_fft=N_FFT):
+    """librosa.filters.mel(sr, n_fft, n_mels) (Slaney scale + normalisation) -- what whisper ships as mel_filters.npz."""
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=float)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=float)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, sr / 2, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(sr / 2), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def log_mel(pcm_i16: np.ndarray, n_mels=80) -> np.ndarray:
+    """whisper.log_mel_spectrogram(audio, n_mels, padding=N_SAMPLES)[:, :3000] for int16 16 kHz audio."""
+    audio = torch.from_numpy(pcm_i16.astype(np.float32) / 32768.0)
+    audio = F.pad(audio, (0, N_SAMPLES))
+    window = torch.hann_window(N_FFT)
+    stft = torch.stft(audio, N_FFT, HOP, window=window, return_complex=True)
+    mag = stft[..., :-1].abs() ** 2
+    mel = torch.from_numpy(mel_filters(n_mels)) @ mag
+    log_spec = torch.clamp(mel, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    log_spec = (log_spec + 4.0) / 4.0
+    return log_spec[:, :N_FRAMES].numpy()
+
+
+def sinusoids(length, channels, max_timescale=10000):
+    inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    st = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(st), torch.cos(st)], dim=1)
+
+
+def encoder_forward(mel: np.ndarray, W: dict, dims: dict) -> np.ndarray:
+    """AudioEncoder.forward on one [n_mels, 3000] log-mel window -> [1500, n_state] (float32)."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    d, H = dims["n_state"], dims["n_head"]
+    x = t(mel)[None]
+    x = F.gelu(F.conv1d(x, t(W["conv1.weight"]), t(W["conv1.bias"]), padding=1))
+    x = F.gelu(F.conv1d(x, t(W["conv2.weight"]), t(W["conv2.bias"]), stride=2, padding=1))
+    x = x.permute(0, 2, 1)
+    x = x + sinusoids(dims["n_ctx"], d)
+    for l in range(dims["n_layer"]):
+        p = f"blocks.{l}."
+        h = F.layer_norm(x, (d,), t(W[p + "attn_ln.weight"]), t(W[p + "attn_ln.bias"]))
+        q = F.linear(h, t(W[p + "attn.query.weight"]), t(W[p + "attn.query.bias"]))
+        k = F.linear(h, t(W[p + "attn.key.weight"]))
+        v = F.linear(h, t(W[p + "attn.value.weight"]), t(W[p + "attn.value.bias"]))
+        n_b, n_t, _ = q.shape
+        scale = (d // H) ** -0.25
+        q = q.view(n_b, n_t, H, -1).permute(0, 2, 1, 3) * scale
+        k = k.view(n_b, n_t, H, -1).permute(0, 2, 3, 1) * scale
+        v = v.view(n_b, n_t, H, -1).permute(0, 2, 1, 3)
+        w = F.softmax((q @ k).float(), dim=-1)
+        a = (w @ v).permute(0, 2, 1, 3).flatten(start_dim=2)
+        x = x + F.linear(a, t(W[p + "attn.out.weight"]), t(W[p + "attn.out.bias"]))
+        h = F.layer_norm(x, (d,), t(W[p + "mlp_ln.weight"]), t(W[p + "mlp_ln.bias"]))
+        h = F.linear(F.gelu(F.linear(h, t(W[p + "mlp.0.weight"]), t(W[p + "mlp.0.bias"]))), t(W[p + "mlp.2.weight"]), t(W[p + "mlp.2.bias"]))
+        x = x + h
+    x = F.layer_norm(x, (d,), t(W["ln_post.weight"]), t(W["ln_post.bias"]))
+    return x[0].numpy()

@@ -93,6 +93,7 @@ void pce_destroy(pce_ctx *c)
                       &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc, &c->pi_rr, &c->pi_items, &c->pi_tw, &c->pi_dl, &c->pi_runs, &c->pi_fslice,
                       &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work};
     for (auto b : bufs) b->release();
+    pce_whisper_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -184,7 +185,7 @@ const char *pce_kernel_name(int id)
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
-        "k_stft_max", "k_stft_db"};
+        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -88,6 +88,9 @@ struct pce_ctx {
     std::vector<int64_t> st_off_host;   // float offsets per clip (n_clips+1)
     std::vector<int32_t> st_frames;
 
+    // whisper (opaque: defined in pce_whisper.hip)
+    void *whisper = nullptr;
+
     // profiling
     bool prof = false;
     double prof_ms[PCE_K_COUNT] = {0};
@@ -121,4 +124,5 @@ struct PitchPlan {
 };
 int pitch_plan_make(int64_t nx, double dx, double x1, const pce_pitch_params *p, PitchPlan *pl);
 
+void pce_whisper_free(pce_ctx *c);
 static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }

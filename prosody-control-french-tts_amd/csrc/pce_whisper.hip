@@ -1,0 +1,671 @@
+// pce_whisper.hip -- log-mel spectrogram and Whisper audio encoder (R8) on gfx950.
+//
+// Replaces the device work that whisper_timestamped.transcribe
+// (Code/Aligners/use_whisper_timestamped.py:139,150-163) performs before decoding, as
+// openai-whisper==20240930 defines it (third-party, restated from its published
+// architecture; parity unpinned, checked against a torch fp32 restatement in oracle/):
+//   log_mel_spectrogram: Hann(400) STFT hop 160 (centre, reflect padding), |.|^2, 80 Slaney
+//     mel bands, log10(max(.,1e-10)), max(., max-8), (.+4)/4, 30 s window = 3000 frames
+//   AudioEncoder: conv1d(80->d,k3,p1)+GELU, conv1d(d->d,k3,s2,p1)+GELU, + sinusoid positions,
+//     L x { x += proj(MHA(LN(x)));  x += W2 gelu(W1 LN(x)) },  LN
+//
+// Execution plan:
+//   k_logmel_frames  one wavefront per frame, 400-point DFT as 25 x 16 Cooley-Tukey in LDS (fp32),
+//                    sparse mel bands, per-clip maximum by ordered-int atomicMax
+//   k_logmel_norm    clamp/scale, writes float [80][3000] and the bf16 time-major padded image
+//                    [3002][80] the first convolution reads as an implicit im2col GEMM operand
+//   k_gemm_bf16      C = A B^T on v_mfma_f32_16x16x32_bf16: 128x128x64 tiles, 4 waves x (64x64),
+//                    fp32 accumulate, LDS rows padded to 144 B (conflict-free ds_read_b128),
+//                    fused epilogues (bias, exact GELU, positional add, residual accumulate).
+//                    Both convolutions are this GEMM with overlapping A rows (lda < K): the
+//                    activations are time-major with zero pad rows, so "im2col" is just a stride.
+//   k_layernorm      one wavefront per row, fp32 statistics
+//   k_attention      flash-style forward per (clip, head, 64 queries): QK^T and PV on MFMA,
+//                    online softmax in registers with DPP row reductions, K / V^T tiles in LDS
+// The residual stream is fp32, every GEMM operand bf16.  Roofline: MFMA (dense bf16).
+#include "pce_internal.h"
+#include <cmath>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __bf16 bf16;
+
+constexpr int W_NFFT = 400, W_HOP = 160, W_BINS = 201, W_FRAMES = 3000, W_SAMPLES = 480000;
+constexpr int W_CTX = 1500;
+constexpr double W_PI = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------
+// log-mel
+// ---------------------------------------------------------------------------
+struct MelTables {            // device pointers
+    const float2 *w16;        // [16]      exp(-2 pi i m / 16)
+    const float2 *w400;       // [25][16]  exp(-2 pi i n2 k1 / 400)
+    const float2 *w25;        // [25]      exp(-2 pi i m / 25)
+    const float *window;      // [400]     periodic Hann
+    const int *mel_lo;        // [n_mels]  first bin of band
+    const int *mel_n;         // [n_mels]  number of bins
+    const int *mel_off;       // [n_mels]  offset into mel_w
+    const float *mel_w;       // packed weights
+};
+
+__device__ __forceinline__ unsigned int f32_order_key(float f)
+{
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_key(unsigned int k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict__ pcm, const int64_t *__restrict__ clip_off, int n_mels,
+                                                      MelTables T, float *__restrict__ logspec /* [clip][n_mels][3000] */,
+                                                      unsigned int *__restrict__ clip_max)
+{
+    __shared__ float xs[4][W_NFFT];
+    __shared__ float2 ys[4][25 * 16];
+    __shared__ float pw[4][W_BINS + 3];
+    __shared__ float2 s_w16[16], s_w25[25], s_w400[25 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 16; i += 256) s_w16[i] = T.w16[i];
+    for (int i = tid; i < 25; i += 256) s_w25[i] = T.w25[i];
+    for (int i = tid; i < 400; i += 256) s_w400[i] = T.w400[i];
+    __syncthreads();
+    const int clip = blockIdx.y;
+    const int64_t base = clip_off[clip], len = min<int64_t>(clip_off[clip + 1] - base, (int64_t)W_SAMPLES);
+    float vmax = -1e30f;
+    for (int frame = blockIdx.x * 4 + wv; frame < W_FRAMES; frame += gridDim.x * 4) {
+        // windowed frame, centre = frame*160, reflect padding at the start, zeros past the audio
+        for (int n = lane; n < W_NFFT; n += 64) {
+            int64_t i = (int64_t)frame * W_HOP - W_NFFT / 2 + n;
+            if (i < 0) i = -i;
+            const float v = (i < len) ? (float)pcm[base + i] * (1.0f / 32768.0f) : 0.0f;
+            xs[wv][n] = v * T.window[n];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        // stage A: Y[n2][k1] = sum_{n1<16} x[25 n1 + n2] W16^{n1 k1}, then twiddle W400^{n2 k1}
+        for (int o = lane; o < 400; o += 64) {
+            const int n2 = o >> 4, k1 = o & 15;
+            float re = 0.f, im = 0.f;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) {
+                const float x = xs[wv][25 * n1 + n2];
+                const float2 w = s_w16[(n1 * k1) & 15];
+                re = fmaf(x, w.x, re); im = fmaf(x, w.y, im);
+            }
+            const float2 t = s_w400[o];
+            ys[wv][o] = make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        // stage B: X[k1 + 16 k2] = sum_{n2<25} Y[n2][k1] W25^{n2 k2}; only k <= 200 is needed
+        for (int k = lane; k < W_BINS; k += 64) {
+            const int k1 = k & 15, k2 = k >> 4;
+            float re = 0.f, im = 0.f;
+            int m = 0;
+            for (int n2 = 0; n2 < 25; n2++) {
+                const float2 y = ys[wv][n2 * 16 + k1];
+                const float2 w = s_w25[m];
+                re += y.x * w.x - y.y * w.y; im += y.x * w.y + y.y * w.x;
+                m += k2; if (m >= 25) m -= 25;
+            }
+            pw[wv][k] = re * re + im * im;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        for (int b = lane; b < n_mels; b += 64) {
+            const int lo = T.mel_lo[b], cnt = T.mel_n[b];
+            const float *w = T.mel_w + T.mel_off[b];
+            float acc = 0.f;
+            for (int i = 0; i < cnt; i++) acc = fmaf(w[i], pw[wv][lo + i], acc);
+            const float lg = log10f(fmaxf(acc, 1e-10f));
+            logspec[((int64_t)clip * n_mels + b) * W_FRAMES + frame] = lg;
+            vmax = fmaxf(vmax, lg);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    }
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    if (lane == 0) atomicMax(clip_max + clip, f32_order_key(vmax));
+}
+
+// out_f32 [clip][n_mels][3000];  out_tm bf16 [clip][3002][n_mels] (rows 0 and 3001 stay zero)
+__global__ __launch_bounds__(256) void k_logmel_norm(float *__restrict__ logspec, const unsigned int *__restrict__ clip_max, int n_mels,
+                                                    bf16 *__restrict__ out_tm)
+{
+    __shared__ float tile[64][65];
+    const int clip = blockIdx.z, f0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const float floor_v = f32_from_key(clip_max[clip]) - 8.0f;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int b = b0 + r, f = f0 + tx;
+        if (b < n_mels && f < W_FRAMES) {
+            float *p = logspec + ((int64_t)clip * n_mels + b) * W_FRAMES + f;
+            const float v = (fmaxf(*p, floor_v) + 4.0f) / 4.0f;
+            *p = v; tile[r][tx] = v;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int f = f0 + r, b = b0 + tx;
+        if (b < n_mels && f < W_FRAMES) out_tm[((int64_t)clip * (W_FRAMES + 2) + f + 1) * n_mels + b] = (bf16)tile[tx][r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GEMM  C[M x N] = A[M x K] * B[N x K]^T  (bf16 in, fp32 accumulate)
+// ---------------------------------------------------------------------------
+enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_GELU_POS_F32 = 2, EPI_RESID_F32 = 3 };
+constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_LD = G_BK + 8;     // LDS row = 72 bf16 = 144 B
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
+                                                  const bf16 *__restrict__ B, int M, int N, int K,
+                                                  const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
+                                                  const float *__restrict__ pos, int pos_T)
+{
+    __shared__ __attribute__((aligned(16))) bf16 sA[G_BM * G_LD];
+    __shared__ __attribute__((aligned(16))) bf16 sB[G_BN * G_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;                     // 2 x 2 waves, each 64 x 64
+    const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+    A += (int64_t)blockIdx.z * a_batch;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += G_BK) {
+        // stage: 128 rows x 64 k = 1024 16-byte chunks per operand, 4 per thread
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+            int ar = m0 + row; if (ar >= M) ar = M - 1;
+            const uint4 va = *reinterpret_cast<const uint4 *>(A + (int64_t)ar * lda + k0 + kc);
+            const uint4 vb = *reinterpret_cast<const uint4 *>(B + (int64_t)(n0 + row) * K + k0 + kc);
+            *reinterpret_cast<uint4 *>(&sA[row * G_LD + kc]) = va;
+            *reinterpret_cast<uint4 *>(&sB[row * G_LD + kc]) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < G_BK; kk += 32) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const bf16x8 *>(&sA[(wr * 64 + i * 16 + fr) * G_LD + kk + fq * 8]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = *reinterpret_cast<const bf16x8 *>(&sB[(wc * 64 + j * 16 + fr) * G_LD + kk + fq * 8]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int col = n0 + wc * 64 + j * 16 + fr;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + wr * 64 + i * 16 + fq * 4 + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                const int64_t o = (int64_t)blockIdx.z * c_batch + (int64_t)row * ldc + col;
+                if (EPI == EPI_BF16) reinterpret_cast<bf16 *>(Cv)[o] = (bf16)v;
+                else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16 *>(Cv)[o] = (bf16)gelu_exact(v);
+                else if (EPI == EPI_GELU_POS_F32) reinterpret_cast<float *>(Cv)[o] = gelu_exact(v) + pos[(int64_t)(row % pos_T) * N + col];
+                else reinterpret_cast<float *>(Cv)[o] += v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dimension (one wavefront per row)
+// ---------------------------------------------------------------------------
+template <class OUT>
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                                  int64_t rows, int d, OUT *__restrict__ out)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += xr[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)d;
+    float q = 0.f;
+    for (int i = lane; i < d; i += 64) { const float t = xr[i] - mean; q += t * t; }
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float inv = rsqrtf(q / (float)d + 1e-5f);
+    for (int i = lane; i < d; i += 64) out[row * d + i] = (OUT)((xr[i] - mean) * inv * w[i] + b[i]);
+}
+
+// ---------------------------------------------------------------------------
+// attention forward: softmax(Q K^T / sqrt(64)) V for one (clip, head, 64 queries)
+// ---------------------------------------------------------------------------
+constexpr int AT_LD = 72;
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_max16(float v)
+{
+    v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float row_sum16f(float v)
+{
+    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qkv /* [clips*S][3 d] */, int S, int d_model,
+                                                  bf16 *__restrict__ out /* [clips*S][d] */)
+{
+    __shared__ __attribute__((aligned(16))) bf16 sK[64 * AT_LD];         // [key][d]
+    __shared__ __attribute__((aligned(16))) bf16 sVt[64 * AT_LD];        // [d][key]
+    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * AT_LD];      // per wave [query][key]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int head = blockIdx.y, clip = blockIdx.z, q0 = blockIdx.x * 64;
+    const int64_t ld = 3 * (int64_t)d_model;
+    const bf16 *base = qkv + (int64_t)clip * S * ld + head * 64;
+    // Q fragments (A operand): row = query fr of this wave's 16, k = d
+    bf16x8 qf[2];
+    {
+        int qr = q0 + wv * 16 + fr; if (qr >= S) qr = S - 1;
+        const bf16 *qp = base + (int64_t)qr * ld;
+        qf[0] = *reinterpret_cast<const bf16x8 *>(qp + fq * 8);
+        qf[1] = *reinterpret_cast<const bf16x8 *>(qp + 32 + fq * 8);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { m_run[r] = -1e30f; l_run[r] = 0.f; }
+    const float scale = 0.125f;                                        // (64^-0.25)^2
+    for (int k0 = 0; k0 < S; k0 += 64) {
+        __syncthreads();
+        // stage K [key][d] and V^T [d][key]: 64 x 64 each = 512 16-byte chunks, 2 per thread
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int c = tid + 256 * i, key = c >> 3, dc = (c & 7) * 8;
+            int kr = k0 + key; if (kr >= S) kr = S - 1;
+            const bf16 *kp = base + (int64_t)kr * ld + d_model + dc;
+            *reinterpret_cast<uint4 *>(&sK[key * AT_LD + dc]) = *reinterpret_cast<const uint4 *>(kp);
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(kp + d_model);
+#pragma unroll
+            for (int e = 0; e < 8; e++) sVt[(dc + e) * AT_LD + key] = v[e];
+        }
+        __syncthreads();
+        // S = Q K^T : 16 queries x 64 keys per wave
+        f32x4 sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(&sK[(j * 16 + fr) * AT_LD + kk * 32 + fq * 8]);
+                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, sc[j], 0, 0, 0);
+            }
+        }
+        // online softmax; this lane holds rows fq*4 + r, column fr of each of the 4 key groups
+        float p[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool valid = (k0 + j * 16 + fr) < S;
+                const float v = valid ? sc[j][r] * scale : -1e30f;
+                p[j][r] = v; mx = fmaxf(mx, v);
+            }
+            mx = row_max16(mx);
+            const float m_new = fmaxf(m_run[r], mx);
+            const float corr = __expf(m_run[r] - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const float e = __expf(p[j][r] - m_new); p[j][r] = e; sum += e; }
+            sum = row_sum16f(sum);
+            l_run[r] = l_run[r] * corr + sum;
+            m_run[r] = m_new;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j][r] *= corr;
+        }
+        // P -> LDS (row-major [query][key]) -> A fragments
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sP[wv][(fq * 4 + r) * AT_LD + j * 16 + fr] = (bf16)p[j][r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const bf16x8 pf = *reinterpret_cast<const bf16x8 *>(&sP[wv][fr * AT_LD + kk * 32 + fq * 8]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(&sVt[(j * 16 + fr) * AT_LD + kk * 32 + fq * 8]);
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int qr = q0 + wv * 16 + fq * 4 + r;
+        if (qr >= S) continue;
+        const float inv = 1.0f / l_run[r];
+        bf16 *op = out + ((int64_t)clip * S + qr) * d_model + head * 64;
+#pragma unroll
+        for (int j = 0; j < 4; j++) op[j * 16 + fr] = (bf16)(o[j][r] * inv);
+    }
+}
+
+__global__ void k_f32_to_bf16(const float *__restrict__ in, bf16 *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16)in[i];
+}
+
+// librosa.filters.mel(sr=16000, n_fft=400, n_mels) (Slaney scale and normalisation), float32
+void mel_filterbank(int n_mels, std::vector<float> &dense)
+{
+    const double sr = 16000.0, f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp; };
+    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m; };
+    std::vector<double> mel_f((size_t)n_mels + 2), fft_f(W_BINS);
+    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(sr / 2);
+    for (int i = 0; i < n_mels + 2; i++) mel_f[(size_t)i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    for (int k = 0; k < W_BINS; k++) fft_f[(size_t)k] = (sr / 2) * k / (W_BINS - 1);
+    dense.assign((size_t)n_mels * W_BINS, 0.f);
+    for (int i = 0; i < n_mels; i++) {
+        const double enorm = 2.0 / (mel_f[(size_t)i + 2] - mel_f[(size_t)i]);
+        for (int k = 0; k < W_BINS; k++) {
+            const double lower = -(mel_f[(size_t)i] - fft_f[(size_t)k]) / (mel_f[(size_t)i + 1] - mel_f[(size_t)i]);
+            const double upper = (mel_f[(size_t)i + 2] - fft_f[(size_t)k]) / (mel_f[(size_t)i + 2] - mel_f[(size_t)i + 1]);
+            const double w = std::max(0.0, std::min(lower, upper));
+            dense[(size_t)i * W_BINS + k] = (float)(w * enorm);
+        }
+    }
+}
+
+struct WhisperState {
+    pce_whisper_dims dims{};
+    bool loaded = false;
+    DevBuf tables, logspec, clipmax, mel_tm, w_bf16, w_f32, pos;
+    DevBuf c1_out, resid, ln_out, qkv, attn, hidden, final_out;
+    MelTables mt{};
+    int mel_nmels = 0;
+    int32_t n_clips_mel = -1, n_clips_enc = -1;
+    // offsets (elements) into w_bf16 / w_f32
+    struct Layer { size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, ln2_w, ln2_b, m1_w, m1_b, m2_w, m2_b; };
+    size_t c1_w = 0, c1_b = 0, c2_w = 0, c2_b = 0, lnp_w = 0, lnp_b = 0;
+    std::vector<Layer> layers;
+};
+
+WhisperState *ws_of(pce_ctx *c)
+{
+    if (!c->whisper) c->whisper = new WhisperState();
+    return static_cast<WhisperState *>(c->whisper);
+}
+
+int mel_setup(pce_ctx *c, WhisperState *w, int n_mels)
+{
+    if (w->mel_nmels == n_mels) return PCE_OK;
+    std::vector<float> dense; mel_filterbank(n_mels, dense);
+    std::vector<int> lo((size_t)n_mels), cnt((size_t)n_mels), off((size_t)n_mels);
+    std::vector<float> packed;
+    for (int i = 0; i < n_mels; i++) {
+        int a = 0, b = W_BINS;
+        while (a < W_BINS && dense[(size_t)i * W_BINS + a] == 0.f) a++;
+        while (b > a && dense[(size_t)i * W_BINS + b - 1] == 0.f) b--;
+        lo[(size_t)i] = a; cnt[(size_t)i] = b - a; off[(size_t)i] = (int)packed.size();
+        for (int k = a; k < b; k++) packed.push_back(dense[(size_t)i * W_BINS + k]);
+    }
+    std::vector<float> w16(32), w25(50), w400(800), win(W_NFFT);
+    for (int m = 0; m < 16; m++) { w16[2 * (size_t)m] = (float)std::cos(2 * W_PI * m / 16); w16[2 * (size_t)m + 1] = (float)-std::sin(2 * W_PI * m / 16); }
+    for (int m = 0; m < 25; m++) { w25[2 * (size_t)m] = (float)std::cos(2 * W_PI * m / 25); w25[2 * (size_t)m + 1] = (float)-std::sin(2 * W_PI * m / 25); }
+    for (int n2 = 0; n2 < 25; n2++)
+        for (int k1 = 0; k1 < 16; k1++) {
+            const double a = 2 * W_PI * (n2 * k1) / 400.0;
+            w400[2 * (size_t)(n2 * 16 + k1)] = (float)std::cos(a); w400[2 * (size_t)(n2 * 16 + k1) + 1] = (float)-std::sin(a);
+        }
+    for (int n = 0; n < W_NFFT; n++) win[(size_t)n] = (float)(0.5 - 0.5 * std::cos(2 * W_PI * n / W_NFFT));
+    // one buffer: [w16 | w400 | w25 | window | lo | cnt | off | packed]
+    const size_t bytes = sizeof(float) * (32 + 800 + 50 + W_NFFT + packed.size()) + sizeof(int) * 3 * (size_t)n_mels + 64;
+    PCE_HIP(c, w->tables.reserve(bytes));
+    char *d = w->tables.as<char>(); size_t o = 0;
+    auto put = [&](const void *src, size_t n) -> const void * {
+        (void)hipMemcpyAsync(d + o, src, n, hipMemcpyHostToDevice, c->stream);
+        const void *p = d + o; o += (n + 15) & ~(size_t)15; return p;
+    };
+    w->mt.w16 = (const float2 *)put(w16.data(), sizeof(float) * 32);
+    w->mt.w400 = (const float2 *)put(w400.data(), sizeof(float) * 800);
+    w->mt.w25 = (const float2 *)put(w25.data(), sizeof(float) * 50);
+    w->mt.window = (const float *)put(win.data(), sizeof(float) * W_NFFT);
+    w->mt.mel_lo = (const int *)put(lo.data(), sizeof(int) * (size_t)n_mels);
+    w->mt.mel_n = (const int *)put(cnt.data(), sizeof(int) * (size_t)n_mels);
+    w->mt.mel_off = (const int *)put(off.data(), sizeof(int) * (size_t)n_mels);
+    w->mt.mel_w = (const float *)put(packed.data(), sizeof(float) * packed.size());
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    w->mel_nmels = n_mels;
+    return PCE_OK;
+}
+
+template <int EPI>
+void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const bf16 *B, int M, int N, int K, const float *bias,
+                 void *C, int64_t ldc, int64_t c_batch, int batch, const float *pos = nullptr, int pos_T = 1)
+{
+    dim3 grid((unsigned)(N / G_BN), (unsigned)div_up(M, G_BM), (unsigned)batch);
+    hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(256), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T);
+}
+
+} // namespace
+
+void pce_whisper_free(pce_ctx *c)
+{
+    if (!c->whisper) return;
+    WhisperState *w = static_cast<WhisperState *>(c->whisper);
+    DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
+                      &w->ln_out, &w->qkv, &w->attn, &w->hidden, &w->final_out};
+    for (auto b : bufs) b->release();
+    delete w;
+    c->whisper = nullptr;
+}
+
+extern "C" {
+
+int pce_logmel_run(pce_ctx *c, int32_t n_mels)
+{
+    if (!c) return PCE_E_INVALID;
+    if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
+    if (c->rate != 16000) return pce_fail(c, PCE_E_INVALID, "log-mel needs 16 kHz audio (got %d Hz): resample on the host first", c->rate);
+    if (n_mels <= 0 || n_mels > 128) return pce_fail(c, PCE_E_INVALID, "n_mels %d out of range", n_mels);
+    PCE_HIP(c, hipSetDevice(c->device));
+    WhisperState *w = ws_of(c);
+    int rc = mel_setup(c, w, n_mels);
+    if (rc) return rc;
+    const int32_t n = c->n_clips;
+    const size_t tm_elems = (size_t)n * (W_FRAMES + 2) * (size_t)n_mels + 512;
+    PCE_HIP(c, w->logspec.reserve(sizeof(float) * (size_t)n * (size_t)n_mels * W_FRAMES));
+    PCE_HIP(c, w->clipmax.reserve(sizeof(unsigned int) * (size_t)n));
+    PCE_HIP(c, w->mel_tm.reserve(sizeof(bf16) * tm_elems));
+    PCE_HIP(c, hipMemsetAsync(w->clipmax.p, 0, sizeof(unsigned int) * (size_t)n, c->stream));
+    PCE_HIP(c, hipMemsetAsync(w->mel_tm.p, 0, sizeof(bf16) * tm_elems, c->stream));
+    {
+        KernelTimer t(c, PCE_K_LOGMEL);
+        hipLaunchKernelGGL(k_logmel_frames, dim3(W_FRAMES / 4 / 5, (unsigned)n), dim3(256), 0, c->stream, c->d_pcm,
+                           c->d_clip_off.as<int64_t>(), (int)n_mels, w->mt, w->logspec.as<float>(), w->clipmax.as<unsigned int>());
+        hipLaunchKernelGGL(k_logmel_norm, dim3(div_up(W_FRAMES, 64), div_up(n_mels, 64), (unsigned)n), dim3(256), 0, c->stream,
+                           w->logspec.as<float>(), w->clipmax.as<unsigned int>(), (int)n_mels, w->mel_tm.as<bf16>());
+    }
+    PCE_HIP(c, hipGetLastError());
+    w->n_clips_mel = n;
+    return PCE_OK;
+}
+
+int pce_logmel_fetch(pce_ctx *c, int32_t clip, float *out)
+{
+    if (!c || !out) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (w->n_clips_mel < 0) return pce_fail(c, PCE_E_STATE, "pce_logmel_fetch before pce_logmel_run");
+    if (clip < 0 || clip >= w->n_clips_mel) return pce_fail(c, PCE_E_INVALID, "clip out of range");
+    const size_t per = (size_t)w->mel_nmels * W_FRAMES;
+    PCE_HIP(c, hipMemcpyAsync(out, w->logspec.as<float>() + per * (size_t)clip, sizeof(float) * per, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    return PCE_OK;
+}
+
+int pce_whisper_load(pce_ctx *c, const pce_whisper_dims *dims, const float *weights, int64_t n_floats)
+{
+    if (!c || !dims || !weights) return PCE_E_INVALID;
+    const int d = dims->n_state, L = dims->n_layer, nm = dims->n_mels;
+    if (d <= 0 || d % 128 || dims->n_head * 64 != d || L <= 0 || dims->n_ctx != W_CTX || nm <= 0 || nm > 128 || (nm % 8))
+        return pce_fail(c, PCE_E_LIMIT, "unsupported encoder dims (need n_state %% 128 == 0, head size 64, n_ctx 1500, n_mels %% 8 == 0)");
+    const int64_t per_layer = 2LL * d + 4LL * d * d + 3LL * d + 2LL * d + 8LL * d * d + 5LL * d;
+    const int64_t expect = (int64_t)d * nm * 3 + d + 3LL * d * d + d + L * per_layer + 2LL * d;
+    if (n_floats != expect) return pce_fail(c, PCE_E_INVALID, "weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)expect);
+    PCE_HIP(c, hipSetDevice(c->device));
+    WhisperState *w = ws_of(c);
+    w->dims = *dims; w->loaded = false; w->layers.assign((size_t)L, {});
+    // host repack: bf16-bound matrices (as fp32, converted on the device) and fp32 vectors
+    std::vector<float> mats, vecs;
+    auto add_vec = [&](const float *p, size_t n) { size_t o = vecs.size(); vecs.insert(vecs.end(), p, p + n); return o; };
+    auto add_zero_vec = [&](size_t n) { size_t o = vecs.size(); vecs.insert(vecs.end(), n, 0.f); return o; };
+    const float *p = weights;
+    {   // conv1 [d][nm][3] -> [d][K1p] with k-major columns (k*nm + ci), zero padded to a multiple of 64
+        const int K1 = 3 * nm, K1p = (int)div_up(K1, 64) * 64;
+        w->c1_w = mats.size(); mats.resize(mats.size() + (size_t)d * K1p, 0.f);
+        for (int co = 0; co < d; co++)
+            for (int ci = 0; ci < nm; ci++)
+                for (int k = 0; k < 3; k++) mats[w->c1_w + (size_t)co * K1p + (size_t)k * nm + ci] = p[((size_t)co * nm + ci) * 3 + k];
+        p += (size_t)d * nm * 3;
+        w->c1_b = add_vec(p, (size_t)d); p += d;
+    }
+    {   // conv2 [d][d][3] -> [d][3 d]
+        w->c2_w = mats.size(); mats.resize(mats.size() + (size_t)d * 3 * d, 0.f);
+        for (int co = 0; co < d; co++)
+            for (int ci = 0; ci < d; ci++)
+                for (int k = 0; k < 3; k++) mats[w->c2_w + (size_t)co * 3 * d + (size_t)k * d + ci] = p[((size_t)co * d + ci) * 3 + k];
+        p += (size_t)d * d * 3;
+        w->c2_b = add_vec(p, (size_t)d); p += d;
+    }
+    for (int l = 0; l < L; l++) {
+        WhisperState::Layer &ly = w->layers[(size_t)l];
+        ly.ln1_w = add_vec(p, (size_t)d); p += d; ly.ln1_b = add_vec(p, (size_t)d); p += d;
+        // q.w q.b k.w v.w v.b -> fused [3d][d], bias [q.b | 0 | v.b]
+        ly.qkv_w = mats.size(); mats.resize(mats.size() + (size_t)3 * d * d);
+        const float *qw = p, *qb = p + (size_t)d * d, *kw = qb + d, *vw = kw + (size_t)d * d, *vb = vw + (size_t)d * d;
+        std::copy(qw, qw + (size_t)d * d, mats.begin() + (ptrdiff_t)ly.qkv_w);
+        std::copy(kw, kw + (size_t)d * d, mats.begin() + (ptrdiff_t)(ly.qkv_w + (size_t)d * d));
+        std::copy(vw, vw + (size_t)d * d, mats.begin() + (ptrdiff_t)(ly.qkv_w + 2 * (size_t)d * d));
+        ly.qkv_b = add_vec(qb, (size_t)d); add_zero_vec((size_t)d); add_vec(vb, (size_t)d);
+        p = vb + d;
+        ly.out_w = mats.size(); mats.insert(mats.end(), p, p + (size_t)d * d); p += (size_t)d * d;
+        ly.out_b = add_vec(p, (size_t)d); p += d;
+        ly.ln2_w = add_vec(p, (size_t)d); p += d; ly.ln2_b = add_vec(p, (size_t)d); p += d;
+        ly.m1_w = mats.size(); mats.insert(mats.end(), p, p + (size_t)4 * d * d); p += (size_t)4 * d * d;
+        ly.m1_b = add_vec(p, (size_t)4 * d); p += 4 * d;
+        ly.m2_w = mats.size(); mats.insert(mats.end(), p, p + (size_t)4 * d * d); p += (size_t)4 * d * d;
+        ly.m2_b = add_vec(p, (size_t)d); p += d;
+    }
+    w->lnp_w = add_vec(p, (size_t)d); p += d; w->lnp_b = add_vec(p, (size_t)d); p += d;
+    // sinusoid positions [1500][d]
+    std::vector<float> pos((size_t)W_CTX * d);
+    {
+        const int half = d / 2;
+        const double inc = std::log(10000.0) / (half - 1);
+        for (int t = 0; t < W_CTX; t++)
+            for (int i = 0; i < half; i++) {
+                const float inv = (float)std::exp(-inc * i);
+                const float a = (float)t * inv;
+                pos[(size_t)t * d + i] = std::sin(a); pos[(size_t)t * d + half + i] = std::cos(a);
+            }
+    }
+    DevBuf tmp;
+    PCE_HIP(c, tmp.reserve(sizeof(float) * mats.size()));
+    PCE_HIP(c, w->w_bf16.reserve(sizeof(bf16) * mats.size() + 256));
+    PCE_HIP(c, w->w_f32.reserve(sizeof(float) * vecs.size()));
+    PCE_HIP(c, w->pos.reserve(sizeof(float) * pos.size()));
+    PCE_HIP(c, hipMemcpyAsync(tmp.p, mats.data(), sizeof(float) * mats.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->w_f32.p, vecs.data(), sizeof(float) * vecs.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->pos.p, pos.data(), sizeof(float) * pos.size(), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up((int64_t)mats.size(), 256)), dim3(256), 0, c->stream, tmp.as<float>(),
+                       w->w_bf16.as<bf16>(), (int64_t)mats.size());
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    w->loaded = true;
+    return PCE_OK;
+}
+
+int pce_whisper_encode_run(pce_ctx *c)
+{
+    if (!c) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (!w->loaded) return pce_fail(c, PCE_E_STATE, "pce_whisper_encode_run before pce_whisper_load");
+    if (w->n_clips_mel < 0 || w->mel_nmels != w->dims.n_mels) return pce_fail(c, PCE_E_STATE, "run pce_logmel_run(n_mels of the model) first");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int d = w->dims.n_state, L = w->dims.n_layer, nm = w->dims.n_mels, H = w->dims.n_head;
+    const int n = w->n_clips_mel;
+    const int64_t M = (int64_t)n * W_CTX;
+    if (M > INT32_MAX) return pce_fail(c, PCE_E_LIMIT, "too many clips for one encoder batch");
+    const int K1p = (int)div_up(3 * nm, 64) * 64;
+    const size_t c1_elems = (size_t)n * (W_FRAMES + 2) * (size_t)d + 4096;
+    PCE_HIP(c, w->c1_out.reserve(sizeof(bf16) * c1_elems));
+    PCE_HIP(c, w->resid.reserve(sizeof(float) * (size_t)M * d));
+    PCE_HIP(c, w->ln_out.reserve(sizeof(bf16) * (size_t)M * d));
+    PCE_HIP(c, w->qkv.reserve(sizeof(bf16) * (size_t)M * 3 * d));
+    PCE_HIP(c, w->attn.reserve(sizeof(bf16) * (size_t)M * d));
+    PCE_HIP(c, w->hidden.reserve(sizeof(bf16) * (size_t)M * 4 * d));
+    PCE_HIP(c, w->final_out.reserve(sizeof(float) * (size_t)M * d));
+    const bf16 *Wb = w->w_bf16.as<bf16>();
+    const float *Wf = w->w_f32.as<float>();
+    KernelTimer t(c, PCE_K_WHISPER_ENC);
+    PCE_HIP(c, hipMemsetAsync(w->c1_out.p, 0, sizeof(bf16) * c1_elems, c->stream));
+    // conv1: per clip, A row t starts at padded row t (= t-1 unpadded), K = 3 n_mels (padded to K1p with zero weights)
+    launch_gemm<EPI_GELU_BF16>(c, w->mel_tm.as<bf16>(), nm, (int64_t)(W_FRAMES + 2) * nm, Wb + w->c1_w, W_FRAMES, d, K1p, Wf + w->c1_b,
+                               w->c1_out.as<bf16>() + d, d, (int64_t)(W_FRAMES + 2) * d, n);
+    // conv2 (stride 2): A row t' starts at padded row 2 t', K = 3 d, lda = 2 d; epilogue adds the positional embedding
+    launch_gemm<EPI_GELU_POS_F32>(c, w->c1_out.as<bf16>(), 2 * (int64_t)d, (int64_t)(W_FRAMES + 2) * d, Wb + w->c2_w, W_CTX, d, 3 * d,
+                                  Wf + w->c2_b, w->resid.as<float>(), d, (int64_t)W_CTX * d, n, w->pos.as<float>(), W_CTX);
+    for (int l = 0; l < L; l++) {
+        const WhisperState::Layer &ly = w->layers[(size_t)l];
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln1_w,
+                           Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
+        launch_gemm<EPI_BF16>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 3 * d, 0, 1);
+        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, 64), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream,
+                           w->qkv.as<bf16>(), W_CTX, d, w->attn.as<bf16>());
+        launch_gemm<EPI_RESID_F32>(c, w->attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, w->resid.as<float>(), d, 0, 1);
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln2_w,
+                           Wf + ly.ln2_b, M, d, w->ln_out.as<bf16>());
+        launch_gemm<EPI_GELU_BF16>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.m1_w, (int)M, 4 * d, d, Wf + ly.m1_b, w->hidden.as<bf16>(), 4 * d, 0, 1);
+        launch_gemm<EPI_RESID_F32>(c, w->hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, (int)M, d, 4 * d, Wf + ly.m2_b, w->resid.as<float>(), d, 0, 1);
+    }
+    hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + w->lnp_w,
+                       Wf + w->lnp_b, M, d, w->final_out.as<float>());
+    PCE_HIP(c, hipGetLastError());
+    w->n_clips_enc = n;
+    return PCE_OK;
+}
+
+int pce_whisper_encode_fetch(pce_ctx *c, int32_t clip, float *out)
+{
+    if (!c || !out) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (w->n_clips_enc < 0) return pce_fail(c, PCE_E_STATE, "pce_whisper_encode_fetch before pce_whisper_encode_run");
+    if (clip < 0 || clip >= w->n_clips_enc) return pce_fail(c, PCE_E_INVALID, "clip out of range");
+    const size_t per = (size_t)W_CTX * (size_t)w->dims.n_state;
+    PCE_HIP(c, hipMemcpyAsync(out, w->final_out.as<float>() + per * (size_t)clip, sizeof(float) * per, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    return PCE_OK;
+}
+
+} // extern "C"

@@ -62,6 +62,10 @@ class PitchSummary(C.Structure):
                 ("t1", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32)]
 
 
+class WhisperDims(C.Structure):
+    _fields_ = [("n_mels", C.c_int32), ("n_ctx", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32)]
+
+
 SLICE_DTYPE = np.dtype([("clip", "<i4"), ("flags", "<i4"), ("begin", "<i8"), ("end", "<i8"), ("x1", "<f8")])
 ENERGY_DTYPE = np.dtype([("n", "<i8"), ("sum_sq", "<i8"), ("sum_sq_wrap16", "<i8"), ("n_loud", "<i8"),
                          ("peak_abs", "<i4"), ("reserved", "<i4")])
@@ -73,7 +77,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -81,6 +85,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_energy_run", "pce_energy_fetch", "pce_lufs_run", "pce_lufs_fetch",
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
+           "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
 
@@ -110,6 +115,11 @@ def load_library() -> C.CDLL:
     lib.pce_stft_db_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_stft_db_fetch.argtypes = [vp, i32, vp]
     lib.pce_stft_db_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    lib.pce_logmel_run.argtypes = [vp, i32]
+    lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
+    lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
+    lib.pce_whisper_encode_run.argtypes = [vp]
+    lib.pce_whisper_encode_fetch.argtypes = [vp, i32, vp]
     lib.pce_profile_enable.argtypes = [vp, C.c_int]
     lib.pce_profile_reset.argtypes = [vp]
     lib.pce_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -273,6 +283,30 @@ class ProsodyEngine:
         p = C.c_void_p(); n = C.c_int64()
         self._check(self._lib.pce_stft_db_device(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    # ---------------------------------------------------------------- whisper front end
+    def logmel_run(self, n_mels: int = 80):
+        self._n_mels = int(n_mels)
+        self._check(self._lib.pce_logmel_run(self._ctx, int(n_mels)))
+
+    def logmel_fetch(self, clip: int) -> np.ndarray:
+        out = np.zeros((self._n_mels, 3000), dtype=np.float32)
+        self._check(self._lib.pce_logmel_fetch(self._ctx, int(clip), out.ctypes.data))
+        return out
+
+    def whisper_load(self, dims: dict, weights: np.ndarray):
+        """``dims``: n_mels, n_ctx, n_state, n_head, n_layer; ``weights``: float32 blob in the order of include/pce.h."""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        self._wdims = WhisperDims(dims["n_mels"], dims["n_ctx"], dims["n_state"], dims["n_head"], dims["n_layer"])
+        self._check(self._lib.pce_whisper_load(self._ctx, C.byref(self._wdims), w.ctypes.data, w.size))
+
+    def whisper_encode_run(self):
+        self._check(self._lib.pce_whisper_encode_run(self._ctx))
+
+    def whisper_encode_fetch(self, clip: int) -> np.ndarray:
+        out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)
+        self._check(self._lib.pce_whisper_encode_fetch(self._ctx, int(clip), out.ctypes.data))
+        return out
 
     # ---------------------------------------------------------------- measurement
     def profile_enable(self, on=True):

@@ -1,0 +1,53 @@
+"""GPU parity of the Whisper front end (R8): log-mel and audio encoder vs a torch fp32 CPU
+restatement (oracle/whisper_oracle.py), fixed-seed synthetic weights.
+
+Tolerances: log-mel <= 2e-3 absolute in Whisper's (x+4)/4 units (fp32 DFT by 25x16
+decomposition vs torch's FFT; values at the max-8 clamp agree to the same band); encoder
+output relative L2 error <= 2e-2 per clip and <= 6e-2 max-abs on unit-variance outputs
+(bf16 MFMA operands, fp32 accumulation and residual stream)."""
+import numpy as np
+import pytest
+
+from oracle import whisper_oracle as WO
+from prosody_control_french_tts_amd import synth, whisper_weights as WW
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def clips():
+    rng = np.random.default_rng(3)
+    return [synth.synth_clip(0, seconds=10.0), synth.synth_clip(1, seconds=3.3),
+            (rng.standard_normal(16000 * 31) * 2500).astype(np.int16),            # longer than the 30 s window
+            np.zeros(16000, dtype=np.int16)]
+
+
+def test_logmel_matches_torch(engine, clips):
+    engine.upload(clips, 16000)
+    engine.logmel_run(80)
+    for i, c in enumerate(clips):
+        got = engine.logmel_fetch(i)
+        want = WO.log_mel(c[:WO.N_SAMPLES], 80)
+        assert got.shape == want.shape == (80, 3000)
+        assert np.max(np.abs(got - want)) <= 2e-3, (i, np.max(np.abs(got - want)))
+
+
+def test_mel_filterbank_known_values():
+    w = WO.mel_filters(80)
+    assert w.shape == (80, 201) and abs(float(w[0, 1]) - 0.02486259) < 1e-7 and (w > 0).sum() == 391
+
+
+@pytest.mark.parametrize("dims", [dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2), WW.DIMS["tiny"]])
+def test_encoder_matches_torch(engine, clips, dims):
+    W = WW.synthetic_weights(dims)
+    engine.upload(clips[:2], 16000)
+    engine.logmel_run(dims["n_mels"])
+    engine.whisper_load(dims, WW.pack(W, dims))
+    engine.whisper_encode_run()
+    for i in range(2):
+        got = engine.whisper_encode_fetch(i)
+        want = WO.encoder_forward(WO.log_mel(clips[i], dims["n_mels"]), W, dims)
+        assert got.shape == want.shape == (1500, dims["n_state"])
+        rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+        assert rel <= 2e-2, rel
+        assert np.max(np.abs(got - want)) <= 6e-2 * max(1.0, float(np.std(want)))
