@@ -25,22 +25,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (never the 2:1-sparsity figure)
 
 
-def algorithmic_bytes(kernel: str, n_clips: int, n_samples: int, n_pitch_frames: int, n_stft_frames: int) -> float:
-    """Algorithmic bytes of ONE launch (PCM 2 B/sample read once per
-    kernel; F0 8 B/frame; STFT-dB 513*4 B/frame; O(1) per clip for the scalar outputs)."""
-    pcm = 2.0 * n_samples * n_clips
-    return {
-        "k_energy": pcm,
-        "k_lufs_pass1": pcm, "k_lufs_pass2": pcm,
-        "k_lufs_scan": 0.0, "k_lufs_gate": 0.0,
-        "k_pitch_frames": pcm + 8.0 * n_pitch_frames * n_clips,
-        "k_pitch_refine": 0.0, "k_pitch_delta": 0.0,
-        "k_pitch_path": 8.0 * n_pitch_frames * n_clips, "k_pitch_median": 8.0 * n_pitch_frames * n_clips,
-        "k_stft_max": pcm,
-        "k_stft_db": pcm + 513 * 4.0 * n_stft_frames * n_clips,
-    }.get(kernel, 0.0)
+def load_pmc_traffic():
+    """HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 for the
+    gfx950 wide-read under-count + WRITE_SIZE, KB -> B; tools/pmc_traffic.py), committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(clips, rate, budget_clips):
@@ -72,6 +68,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips", type=int, default=256, help="clips timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 (default, BASELINE.json configs[1]): F0+energy+LUFS+STFT; c3: c2 + log-mel + Whisper-small encoder")
     args = ap.parse_args()
 
     import torch
@@ -103,7 +101,16 @@ def main():
     n_pitch_frames = int(off[1] - off[0])
     n_stft_frames = 1 + n_samples // 256
 
+    wdims = None
+    if args.workload == "c3":
+        from prosody_control_french_tts_amd import whisper_weights as WW
+        wdims = WW.DIMS["small"]
+        eng.whisper_load(wdims, WW.pack(WW.synthetic_weights(wdims), wdims))       # random-init weights of the architecture
+
     def step():
+        if wdims:
+            eng.logmel_run(wdims["n_mels"])
+            eng.whisper_encode_run()
         eng.energy_run(sl, 500)
         eng.lufs_run(sl)
         eng.pitch_run(sl, params)
@@ -144,21 +151,61 @@ def main():
     assert rec.shape == (args.clips * world, 7)
 
     if rank == 0:
+        # per-kernel figures (HIP events on the engine's stream around every launch)
         kernels = []
         for name, p in prof.items():
             avg_ms = p["total_ms"] / p["launches"]
-            ab = algorithmic_bytes(name, args.clips, n_samples, n_pitch_frames, n_stft_frames)
             kernels.append({"kernel": name, "avg_ms": avg_ms, "launches_per_step": p["launches"] / args.steps,
-                            "ms_per_step": p["total_ms"] / args.steps, "algorithmic_bytes": ab,
-                            "achieved_GBs": ab / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None})
+                            "ms_per_step": p["total_ms"] / args.steps})
         kernels.sort(key=lambda k: -k["ms_per_step"])
+        kt = {k["kernel"]: k for k in kernels}
+        # stages: a stage's algorithmic bytes are moved ONCE by its kernels together; the
+        # intermediates between them (candidates, autocorrelations, chunk states) are not algorithmic traffic
+        pcm = 2.0 * n_samples * args.clips
+        f0_out = 8.0 * n_pitch_frames * args.clips
+        stft_out = 513 * 4.0 * n_stft_frames * args.clips
+        stages = [
+            ("energy (R3/R7)", ["k_energy"], pcm, None),
+            ("lufs (R4)", ["k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate"], pcm, None),
+            ("f0 (R1: Praat AC + path + median)", ["k_pitch_frames", "k_pitch_refine", "k_pitch_delta", "k_pitch_path", "k_pitch_median"],
+             pcm + f0_out, None),
+            ("stft-dB (R10)", ["k_stft_max", "k_stft_db"], pcm + stft_out, None),
+        ]
+        if wdims:
+            d, L = wdims["n_state"], wdims["n_layer"]
+            flop = args.clips * (2.0 * 3000 * d * 240 + 2.0 * 1500 * d * 3 * d
+                                 + L * (2.0 * 1500 * d * 3 * d + 4.0 * 1500 * 1500 * d + 2.0 * 1500 * d * d + 16.0 * 1500 * d * d))
+            stages += [("log-mel (R8)", ["k_logmel"], pcm + 80 * 3000 * 4.0 * args.clips, None),
+                       ("whisper-small encoder (R8)", ["whisper_encoder"], None, flop)]
+        # k_energy runs three times per step (gate, LUFS peak, pitch peak): split its time over the users
+        rows = []
+        for name, ks, nbytes, flops in stages:
+            ms = sum(kt[k]["ms_per_step"] for k in ks if k in kt)
+            if name.startswith("energy") and "k_energy" in kt:
+                ms = kt["k_energy"]["avg_ms"]
+            if ms <= 0:
+                continue
+            dom = max((k for k in ks if k in kt), key=lambda k: kt[k]["ms_per_step"])
+            if flops is None:
+                ach = nbytes / (ms * 1e-3) / 1e9
+                rows.append({"stage": name, "kernels": ks, "dominant_kernel": dom, "ms_per_step": ms, "bound": "hbm",
+                             "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+            else:
+                ach = flops / (ms * 1e-3) / 1e12
+                rows.append({"stage": name, "kernels": ks, "dominant_kernel": dom, "ms_per_step": ms, "bound": "mfma",
+                             "algorithmic_flops": flops, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / MFMA_BF16_PEAK_TFLOPS})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        traffic = load_pmc_traffic()
         roofline = None
-        if kernels:
-            k0 = kernels[0]
-            roofline = {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": k0["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
-                        "note": "dominant kernel by device time; k_pitch_frames is fp64-VALU/LDS bound (about 1e3 flop per "
-                                "algorithmic byte), see DESIGN.md; per-kernel figures in `kernels`"}
+        if rows:
+            r0 = rows[0]
+            t0 = traffic.get(r0["dominant_kernel"]) if traffic else None
+            roofline = {"kernel": r0["dominant_kernel"], "stage": r0["stage"], "bound": r0["bound"], "achieved": r0["achieved"],
+                        "peak": r0["peak"], "unit": r0["unit"], "frac": r0["frac"], "traffic": t0,
+                        "note": "dominant stage by device time; `achieved` = the stage's algorithmic bytes (or flops) / the device time "
+                                "of the stage's kernels.  The F0 stage is fp64-VALU bound (about 1e3 flop per algorithmic byte, "
+                                "DESIGN.md section 3): its HBM fraction is small by construction; `stages` lists every stage."}
         cpu = cpu_baseline(clips, rate, args.cpu_clips) if args.cpu_clips > 0 else None
         info = eng.device_info()
         print(json.dumps({
@@ -166,12 +213,12 @@ def main():
             "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, "
+            "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, "
                                    "energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256; "
-                                   "Whisper-encoder alignment (C3) not included",
+                                   + ("+ log-mel + Whisper-small encoder (synthetic weights, bf16 MFMA)" if wdims else "Whisper-encoder alignment (C3) not included: --workload c3"),
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip"},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
             "device": info["name"], "host_cores": os.cpu_count(),
         }))
     eng.close()
