@@ -45,9 +45,19 @@ __global__ __launch_bounds__(EN_THREADS) void k_energy(const int16_t *__restrict
     const EnWork w = work[blockIdx.x];
     const int64_t a0 = w.g0 & ~(int64_t)7;
     unsigned long long s_sq = 0; int s_wrap = 0; int n_loud = 0; int peak = 0; int s_sum = 0; int m_hi = 0, m_lo = 0;
-    for (int64_t pos = a0 + (int64_t)threadIdx.x * 8; pos < w.g1; pos += (int64_t)EN_THREADS * 8) {
-        const int4 v = *reinterpret_cast<const int4 *>(pcm + pos);
-        const int words[4] = {v.x, v.y, v.z, v.w};
+    // all EN_ITERS 16-byte loads of this lane are issued before the first is consumed (a chunk is at most
+    // EN_ITERS * 4 KiB per wave): the kernel is a pure stream, latency hides only behind bytes in flight
+    int4 v[EN_ITERS];
+    const int64_t p0 = a0 + (int64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int it = 0; it < EN_ITERS; it++) {
+        const int64_t pos = p0 + (int64_t)it * EN_THREADS * 8;
+        v[it] = pos < w.g1 ? *reinterpret_cast<const int4 *>(pcm + pos) : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < EN_ITERS; it++) {
+        const int64_t pos = p0 + (int64_t)it * EN_THREADS * 8;
+        const int words[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int lo = (int)(short)(words[k] & 0xFFFF), hi = words[k] >> 16;

@@ -73,7 +73,8 @@ namespace {
 
 constexpr double PI_D = 3.1415926535897932384626433832795028841972;
 constexpr double LOG2E_D = 1.4426950408889634073599246810018921374266;
-constexpr int PI_WPB = 4;                 // waves (= frames) per block in k_pitch_frames
+constexpr int PI_WPB = 4;                 // waves per block in k_pitch_frames
+constexpr int PI_FPB = 4;                 // frames per work item (one per wave measured fastest: silent frames exit early)
 constexpr int PI_MAXC = 16;               // candidates per frame the kernels can hold
 constexpr int PATH_TILE = 64;
 constexpr int RF_LISTS = 256;             // independent candidate lists (one hot counter would serialise in L2)
@@ -81,7 +82,7 @@ constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte line
 
 struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
-    int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len;
+    int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, tab_lds, pad2;
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -227,17 +228,20 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
     const int nb = (int)gridDim.x;
     int bid = (int)blockIdx.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-    if (bid >= n_work) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int M = P.nfft >> 1;
+    if (bid >= n_work) return;
     const PiWork wk = work[bid];
     const PiSlice s = slices[wk.slice];
-    const int iframe = wk.frame0 + wv;                  // 0-based
-    if (iframe >= s.n_frames) return;
     double2 *bufA = reinterpret_cast<double2 *>(lds) + (size_t)wv * (size_t)(2 * P.zlen);
     double2 *bufB = bufA + P.zlen;
     double *xr = reinterpret_cast<double *>(bufA);      // real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
-    const int M = P.nfft >> 1;
+    // each wavefront walks PI_FPB / PI_WPB frames of the work item (the table copy above is paid once per item)
+    for (int fi = wv; fi < PI_FPB; fi += PI_WPB) {
+    const int iframe = wk.frame0 + fi;                  // 0-based
+    if (iframe >= s.n_frames) break;
     const int64_t fidx = s.frame_off + iframe;
+    wave_sync();                                        // the previous frame's LDS reads are done
 
     // global mean / peak of the slice from the exact integer accumulators
     double globalPeak;
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
         cand[fidx * 32 + 16 + lane] = 0.0;
     }
     if (lane == 0) { ncand[fidx] = n; intensity[fidx] = inten; }
+    }   // frames of this wavefront
 }
 
 // ---------------------------------------------------------------------------
@@ -957,8 +962,9 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             const int Mc = nfft / 2;
             P.zlen = Mc + Mc / 8 + 2;
             P.rr_len = 2 * P.bix + 2;
-            const size_t lds = sizeof(double) * 4 * (size_t)P.zlen * PI_WPB;
-            if (lds > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
+            const size_t lds_waves = sizeof(double) * 4 * (size_t)P.zlen * PI_WPB;
+            if (lds_waves > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
+            P.tab_lds = 0;   // copying the tables into LDS per workgroup measured slower (1.77 vs 1.45 ms) than L1-cached global reads
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
             for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
@@ -987,7 +993,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             if (nf > INT32_MAX) return pce_fail(c, PCE_E_LIMIT, "slice %d has too many frames", i);
             h.n_frames = (int32_t)nf; h.status = c->pi_status[(size_t)i];
             if (nf > max_frames) max_frames = nf;
-            for (int64_t f = 0; f < nf; f += PI_WPB) work.push_back({i, (int32_t)f});
+            for (int64_t f = 0; f < nf; f += PI_FPB) work.push_back({i, (int32_t)f});
         }
         int np2 = 1; while (np2 < max_frames) np2 <<= 1;
         if ((size_t)np2 * sizeof(double) > 128 * 1024) return pce_fail(c, PCE_E_LIMIT, "slice with %lld frames exceeds the %d-frame median limit", (long long)max_frames, 16384);
@@ -1005,7 +1011,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         PCE_HIP(c, c->pi_fslice.reserve(sizeof(int) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_dl.reserve(sizeof(double) * 2 * PI_MAXC * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_rr.reserve(sizeof(double) * (size_t)P.rr_len * (size_t)(total + 1)));
-        PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)PI_WPB * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
+        PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)PI_FPB * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
                                        + sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE));
         PCE_HIP(c, hipMemcpyAsync(c->pi_meta.p, hs.data(), sizeof(PiSlice) * hs.size(), hipMemcpyHostToDevice, c->stream));
         if (!work.empty())
@@ -1038,7 +1044,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             const size_t cnt_bytes = sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE;
             RefineItem *items = reinterpret_cast<RefineItem *>(c->pi_items.as<char>() + cnt_bytes);
             unsigned int *item_count = c->pi_items.as<unsigned int>();
-            const unsigned int list_cap = (unsigned int)(div_up(nb, RF_LISTS) * PI_WPB * (PI_MAXC - 1));
+            const unsigned int list_cap = (unsigned int)(div_up(nb, RF_LISTS) * PI_FPB * (PI_MAXC - 1));
             PCE_HIP(c, hipMemsetAsync(item_count, 0, cnt_bytes, c->stream));
             {
                 KernelTimer t(c, PCE_K_PITCH_FRAMES);

@@ -61,21 +61,39 @@ __device__ __forceinline__ void dft8(float2 a[8])
     }
 }
 
-// One frame: |X[k]|^2-ready magnitudes.  zb: this wave's LDS buffer; w512/w1024: twiddle tables in LDS.
-// Calls sink(k, magnitude) for k = 0..512 (k = lane + 64 t, plus k = 512 on lane 0).
+// Per-lane constants of the transform, loaded once per workgroup into registers: the lane's 16 window
+// taps, its pass-2 / pass-3 twiddles and the untangle twiddles of its 9 bins.
+struct StConst {
+    float2 win[8];      // window[2n], window[2n+1] for n = lane + 64 t
+    float2 tw2[7];      // w512[t * (lane & 7) * 8], t = 1..7
+    float2 tw3[7];      // w512[t * lane],           t = 1..7
+    float2 twu[9];      // w1024[lane + 64 t],       t = 0..8
+};
+__device__ __forceinline__ void load_const(StConst &c, const float *__restrict__ window, const float2 *__restrict__ g512,
+                                           const float2 *__restrict__ g1024, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 8; t++) c.win[t] = *reinterpret_cast<const float2 *>(window + 2 * (lane + 64 * t));
+#pragma unroll
+    for (int t = 1; t < 8; t++) { c.tw2[t - 1] = g512[t * (lane & 7) * 8]; c.tw3[t - 1] = g512[t * lane]; }
+#pragma unroll
+    for (int t = 0; t < 9; t++) c.twu[t] = g1024[min(lane + 64 * t, MC)];
+}
+
+// One frame.  zb: this wave's LDS buffer.  Calls sink(k, magnitude) for k = lane + 64 t (t = 0..7) and k = 512 on lane 0.
 template <class Sink>
-__device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, const StClip &cl, int frame, int hop,
-                                           const float *__restrict__ window, float2 *zb, const float2 *w512, const float2 *w1024,
-                                           int lane, Sink sink)
+__device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, const StClip &cl, int frame, int hop, const StConst &C,
+                                           float2 *zb, int lane, Sink sink)
 {
     float2 a[8];
     const int64_t s0 = (int64_t)frame * hop - NFFT / 2;            // first sample of the centred frame
+    const bool interior = s0 >= 0 && s0 + NFFT <= cl.len && (((cl.pcm_off + s0) & 1) == 0);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int n = lane + 64 * t;                               // complex index, samples 2n and 2n+1
         const int64_t i0 = s0 + 2 * n;
         float x0 = 0.f, x1 = 0.f;
-        if (i0 >= 0 && i0 + 1 < cl.len && (((cl.pcm_off + i0) & 1) == 0)) {
+        if (interior) {
             const int v = *reinterpret_cast<const int *>(pcm + cl.pcm_off + i0);   // 4-byte aligned pair
             x0 = (float)(short)(v & 0xFFFF) * (1.0f / 32768.0f);
             x1 = (float)(v >> 16) * (1.0f / 32768.0f);
@@ -83,7 +101,7 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
             if (i0 >= 0 && i0 < cl.len) x0 = (float)pcm[cl.pcm_off + i0] * (1.0f / 32768.0f);
             if (i0 + 1 >= 0 && i0 + 1 < cl.len) x1 = (float)pcm[cl.pcm_off + i0 + 1] * (1.0f / 32768.0f);
         }
-        a[t] = make_float2(x0 * window[2 * n], x1 * window[2 * n + 1]);
+        a[t] = make_float2(x0 * C.win[t].x, x1 * C.win[t].y);
     }
     // pass 1 (Ns = 1): no twiddles
     dft8(a);
@@ -97,7 +115,7 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
         for (int t = 0; t < 8; t++) a[t] = zb[ZPAD(lane + 64 * t)];
         const int k = lane & 7;
 #pragma unroll
-        for (int t = 1; t < 8; t++) a[t] = cmul(a[t], w512[t * k * 8]);
+        for (int t = 1; t < 8; t++) a[t] = cmul(a[t], C.tw2[t - 1]);
         dft8(a);
         const int base = ((lane - k) << 3) + k;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -112,7 +130,7 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
 #pragma unroll
         for (int t = 0; t < 8; t++) a[t] = zb[ZPAD(lane + 64 * t)];
 #pragma unroll
-        for (int t = 1; t < 8; t++) a[t] = cmul(a[t], w512[t * lane]);
+        for (int t = 1; t < 8; t++) a[t] = cmul(a[t], C.tw3[t - 1]);
         dft8(a);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -129,17 +147,11 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
         const float2 zk = zb[ZPAD(k & (MC - 1))], zm = zb[ZPAD((MC - k) & (MC - 1))];
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-        const float2 x = cadd(e, cmul(w1024[k], o));
-        sink(k, hypotf(x.x, x.y));
+        const float2 x = cadd(e, cmul(C.twu[t], o));
+        sink(k, sqrtf(x.x * x.x + x.y * x.y));      // |x| <= 1024: no overflow; np.abs differs by <= 1 ulp
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void load_tables(float2 *w512, float2 *w1024, const float2 *g512, const float2 *g1024, int tid, int nthreads)
-{
-    for (int i = tid; i < MC; i += nthreads) w512[i] = g512[i];
-    for (int i = tid; i < NBINS; i += nthreads) w1024[i] = g1024[i];
 }
 
 __device__ __forceinline__ int remap_xcd(int bid, int nb) { return ((nb & 7) == 0) ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid; }
@@ -151,13 +163,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_max(const int16_t *__restri
                                                          const float2 *__restrict__ g1024, unsigned int *__restrict__ clip_max)
 {
     __shared__ float2 zbuf[WAVES][ZBUF];
-    __shared__ float2 w512[MC];
-    __shared__ float2 w1024[NBINS + 7];
     __shared__ float red[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int bid = remap_xcd((int)blockIdx.x, (int)gridDim.x);
-    load_tables(w512, w1024, g512, g1024, tid, 64 * WAVES);
-    __syncthreads();
+    StConst C; load_const(C, window, g512, g1024, lane);
     float m = 0.f;
     int clip = 0;
     if (bid < n_tiles) {
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_max(const int16_t *__restri
         for (int fr = wv; fr < F; fr += WAVES) {
             const int frame = tl.frame0 + fr;
             if (frame >= cl.n_frames) break;
-            stft_frame(pcm, cl, frame, hop, window, zbuf[wv], w512, w1024, lane, [&](int, float mag) { m = fmaxf(m, mag); });
+            stft_frame(pcm, cl, frame, hop, C, zbuf[wv], lane, [&](int, float mag) { m = fmaxf(m, mag); });
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -188,14 +197,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_db(const int16_t *__restric
                                                         float amin2, float top_db, float *__restrict__ out)
 {
     __shared__ float2 zbuf[WAVES][ZBUF];
-    __shared__ float2 w512[MC];
-    __shared__ float2 w1024[NBINS + 7];
     __shared__ float tile[NBINS][F + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int bid = remap_xcd((int)blockIdx.x, (int)gridDim.x);
-    load_tables(w512, w1024, g512, g1024, tid, 64 * WAVES);
-    __syncthreads();
     if (bid >= n_tiles) return;
+    StConst C; load_const(C, window, g512, g1024, lane);
     const StTile tl = tiles[bid];
     const StClip cl = clips[tl.clip];
     const float ref = __uint_as_float(clip_max[tl.clip]);
@@ -203,9 +209,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_db(const int16_t *__restric
     const float floor_db = 0.0f - top_db;
     const int nfr = min(F, cl.n_frames - tl.frame0);
     for (int fr = wv; fr < nfr; fr += WAVES) {
-        stft_frame(pcm, cl, tl.frame0 + fr, hop, window, zbuf[wv], w512, w1024, lane, [&](int k, float mag) {
+        stft_frame(pcm, cl, tl.frame0 + fr, hop, C, zbuf[wv], lane, [&](int k, float mag) {
             const float pw = mag * mag;
-            float db = 10.0f * log10f(fmaxf(amin2, pw));
+            float db = 10.0f * __log10f(fmaxf(amin2, pw));
             db -= ref_db;
             tile[k][fr] = fmaxf(db, floor_db);
         });
