@@ -214,7 +214,7 @@ __device__ double2 *fft_wave(double2 *src, double2 *dst, int M, const double2 *_
     return src;
 }
 
-__global__ __launch_bounds__(64 * PI_WPB) void k_pitch_frames(
+__global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
     const int16_t *__restrict__ pcm, const PiSlice *__restrict__ slices, const PiWork *__restrict__ work, int n_work,
     PiParams P, const double *__restrict__ window, const double *__restrict__ windowR,
     const double2 *__restrict__ twM /* exp(-2 pi i m / M), m < M */, const double2 *__restrict__ twN /* exp(-2 pi i k / N), k <= M */,

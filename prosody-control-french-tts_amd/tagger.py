@@ -343,6 +343,42 @@ class SsmlTagger:
                     for seg, pieces in by_seg.items()]
         return pd.DataFrame(seg_rows), pd.DataFrame(syn_rows), pd.DataFrame(synth_rows)
 
+    # -- multi-GPU: utterances sharded by rank, exactly one exchange per table
+    def run_sharded(self, segments: Sequence[SegmentInput], src: MeasurementSource, rank: int, world: int,
+                    allgather: Callable[[np.ndarray], np.ndarray]) -> TaggerResult:
+        """Rank ``rank`` of ``world`` measures only its contiguous block of the segment-sorted list
+        (:func:`shard.shard_range`).  Two padded all-gathers of fp64 records move everything the
+        sequential parts need: the 7 per-segment statistics (Code/audioPipeline.py:391-400) before the
+        baselines, and (segment index, pause, raw pitch / volume / rate) per syntagme before the EMA
+        smoothing, which runs over ALL syntagmes in segment order (:592-602).  Texts are not
+        exchanged: every rank can rebuild them from the TextGrids.  Every rank returns the full tables."""
+        from .shard import SEGMENT_RECORD, shard_range
+        segments = sorted(segments, key=lambda s: segment_sort_key(s.name))
+        lo, hi = shard_range(len(segments), rank, world)
+        mine = segments[lo:hi]
+        res = TaggerResult()
+        local = self.segment_statistics(mine, src)
+        rec = np.array([[s[k] for k in SEGMENT_RECORD] for s in local], dtype=np.float64).reshape(len(local), len(SEGMENT_RECORD))
+        allrec = allgather(rec)
+        res.segment_stats = [dict(zip(SEGMENT_RECORD, map(float, r)), segment=segments[i].name) for i, r in enumerate(allrec)]
+        for s in res.segment_stats:
+            s["wc"] = int(s["wc"])
+        res.baselines = self.baselines(res.segment_stats)
+        rows_local = self.raw_rows(mine, res.baselines[lo:hi], src)
+        index = {s.name: i for i, s in enumerate(segments)}
+        num = np.array([[index[r["segment"]], r["pause"], r["raw_pitch"], r["raw_volume"], r["raw_rate"]] for r in rows_local],
+                       dtype=np.float64).reshape(len(rows_local), 5)
+        allnum = allgather(num)
+        texts = [syn["words"] for seg in segments for syn in self.syntagmes_of(seg)]
+        if len(texts) != len(allnum):
+            raise RuntimeError("gathered syntagme table does not match the TextGrids")
+        res.rows = [{"segment": segments[int(r[0])].name, "syntagme": t, "pause": int(r[1]), "raw_pitch": float(r[2]),
+                     "raw_volume": float(r[3]), "raw_rate": float(r[4])} for r, t in zip(allnum, texts)]
+        if res.rows:
+            res.smooth_pitch, res.smooth_rate = self.smooth(res.rows)
+            res.bdd_ssml, res.bdd_syntagme_ssml, res.bdd_syntagme_for_synth = self.tables(res.rows, res.smooth_pitch, res.smooth_rate)
+        return res
+
     # -- everything
     def run(self, segments: Sequence[SegmentInput], src: MeasurementSource, gather: Optional[Callable] = None) -> TaggerResult:
         """``gather``: optional hook applied to the per-segment statistics (a list of dicts) that

@@ -92,3 +92,40 @@ def test_allgather_records_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+_TAGGER_WORKER = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[3]); sys.path.insert(0, os.path.join(sys.argv[3], "tests"))
+import torch.distributed as dist
+from prosody_control_french_tts_amd import shard, tagger as T
+from test_goldens import FixtureSource, load
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+for sc in load("tagger.json"):
+    tg = T.SsmlTagger(T.ProsodySettings.from_config(sc["config"]), sc["azure_voice"], nlp=T.TablePosTagger(sc["pos_table"]))
+    segs = [T.SegmentInput(s["segment"], [tuple(iv) for iv in s["intervals"]]) for s in sc["segments"]]
+    res = tg.run_sharded(segs, FixtureSource(sc), rank, world, shard.allgather_records)
+    for name, df in (("BDD_ssml.csv", res.bdd_ssml), ("BDD_syntagme_ssml.csv", res.bdd_syntagme_ssml),
+                     ("BDD_syntagme_for_synth.csv", res.bdd_syntagme_for_synth)):
+        path = os.path.join(sys.argv[5], f"r{rank}_{name}")
+        df.to_csv(path, index=False)
+        assert open(path, encoding="utf-8").read() == sc["expected"][name], (rank, name)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_tagger_reproduces_reference_csvs_gloo_world2(tmp_path):
+    """N > 1 path of the SSML tagger: two ranks each measure half of the segments, two all-gathers,
+    and the CSVs equal the reference's (golden G7) on every rank."""
+    script = tmp_path / "t.py"
+    script.write_text(_TAGGER_WORKER)
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
