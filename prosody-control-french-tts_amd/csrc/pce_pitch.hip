@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
     double2 *bufB = bufA + P.zlen;
     double *xr = reinterpret_cast<double *>(bufA);      // real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
     // each wavefront walks PI_FPB / PI_WPB frames of the work item (the table copy above is paid once per item)
-    for (int fi = wv; fi < PI_FPB; fi += PI_WPB) {
+    for (int fi = wv; fi < PI_FPB; fi += (int)(blockDim.x >> 6)) {
     const int iframe = wk.frame0 + fi;                  // 0-based
     if (iframe >= s.n_frames) break;
     const int64_t fidx = s.frame_off + iframe;
@@ -962,8 +962,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             const int Mc = nfft / 2;
             P.zlen = Mc + Mc / 8 + 2;
             P.rr_len = 2 * P.bix + 2;
-            const size_t lds_waves = sizeof(double) * 4 * (size_t)P.zlen * PI_WPB;
-            if (lds_waves > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
+            const size_t lds_wave = sizeof(double) * 4 * (size_t)P.zlen;            // two complex buffers per wavefront
+            if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
             P.tab_lds = 0;   // copying the tables into LDS per workgroup measured slower (1.77 vs 1.45 ms) than L1-cached global reads
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
@@ -1038,7 +1038,10 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         {
             int64_t nb = c->pi_n_work;
             nb = (nb + 7) & ~(int64_t)7;         // multiple of 8 so the XCD remap is a bijection; extra blocks exit
-            const size_t lds = sizeof(double) * 4 * (size_t)P.zlen * PI_WPB;
+            // long windows (44.1 kHz at a 75 Hz floor: 72 KB per wavefront) run fewer wavefronts per workgroup
+            int wpb = PI_WPB;
+            while (wpb > 1 && sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb > 160 * 1024) wpb >>= 1;
+            const size_t lds = sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb;
             if (lds > 64 * 1024)
                 PCE_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pitch_frames), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const size_t cnt_bytes = sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE;
@@ -1048,7 +1051,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             PCE_HIP(c, hipMemsetAsync(item_count, 0, cnt_bytes, c->stream));
             {
                 KernelTimer t(c, PCE_K_PITCH_FRAMES);
-                hipLaunchKernelGGL(k_pitch_frames, dim3((unsigned)nb), dim3(64 * PI_WPB), lds, c->stream, c->d_pcm,
+                hipLaunchKernelGGL(k_pitch_frames, dim3((unsigned)nb), dim3(64 * wpb), lds, c->stream, c->d_pcm,
                                    c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,
                                    c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
                                    c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,

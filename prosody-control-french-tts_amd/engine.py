@@ -323,3 +323,19 @@ class ProsodyEngine:
             if n.value:
                 out[name] = {"total_ms": ms.value, "launches": n.value}
         return out
+
+
+_DEFAULT_ENGINE = None
+
+
+def get_default_engine(device: int = 0) -> ProsodyEngine:
+    """Process-wide engine used by the module-level drop-in functions (``Pipeline.compute_*``)."""
+    global _DEFAULT_ENGINE
+    if _DEFAULT_ENGINE is None:
+        _DEFAULT_ENGINE = ProsodyEngine(device)
+    return _DEFAULT_ENGINE
+
+
+def set_default_engine(engine: ProsodyEngine):
+    global _DEFAULT_ENGINE
+    _DEFAULT_ENGINE = engine

@@ -160,3 +160,44 @@ def test_measure_and_build_ssml_step_matches_cpu_reference_path(engine, excerpts
         p = tmp_path / ("want_" + got_csv.name)
         df.to_csv(p, index=False)
         assert got_csv.read_text(encoding="utf-8") == p.read_text(encoding="utf-8")
+
+
+def test_legacy_pipeline_modules_on_gpu(engine, excerpts, tmp_path):
+    """Legacy ``Code/Pipeline`` API: _calculate_loudness (golden G3, bit-exact), calculate_pitch_segment
+    (oracle restatement of the floors-75/100/150/200 geometric-mean rule) and the aligner's gate (golden G4)."""
+    from prosody_control_french_tts_amd import engine as E
+    from prosody_control_french_tts_amd.Aligners import use_whisper_timestamped as AL
+    from prosody_control_french_tts_amd.Pipeline import compute_loudness_adjustments as LOUD
+    from prosody_control_french_tts_amd.Pipeline import compute_pitch_adjustments as PITCH
+    E.set_default_engine(engine)
+    rate, clips = excerpts
+    for name, pcm in clips.items():
+        _write_wav(tmp_path / name, pcm, rate)
+    cases = json.load(open(os.path.join(G, "rms_db.json")))
+    got = LOUD.loudness_batch([(str(tmp_path / c["file"]), c["start"], c["end"]) for c in cases])
+    for c, v in zip(cases, got):
+        if c["expected"] is None:
+            assert np.isnan(v)
+        elif isinstance(c["expected"], str):
+            assert str(v) == c["expected"]
+        else:
+            assert v == c["expected"]
+    assert LOUD._calculate_loudness(str(tmp_path / "missing.wav"), 0.0, 1.0) == 0
+    # pitch: a few windows per file, compared with the oracle's restatement of the same rule
+    rng = np.random.default_rng(5)
+    req = []
+    for name in sorted(clips)[:4]:
+        for _ in range(3):
+            a = float(rng.uniform(0.0, 0.8)); b = a + float(rng.uniform(0.03, 0.4))
+            req.append((str(tmp_path / name), a, min(b, 1.19)))
+    req.append((str(tmp_path / sorted(clips)[0]), 0.5, 0.4))              # invalid times -> 0
+    req.append((str(tmp_path / sorted(clips)[0]), 0.5, 5.0))              # beyond the file -> 0
+    got = PITCH.pitch_segments_batch(req)
+    for (path, a, b), v in zip(req, got):
+        want = O.legacy_pitch_segment(clips[os.path.basename(path)], rate, a, b)
+        assert (want == 0 and v == 0) or abs(v - want) <= 1e-6 * want, (path, a, b, v, want)
+    # gate
+    gate = [c for c in json.load(open(os.path.join(G, "gate.json"))) if c["file"] in clips]
+    res = AL.check_audio_content_batch([str(tmp_path / c["file"]) for c in gate])
+    for c, (ok, msg) in zip(gate, res):
+        assert ok == c["ok"] and msg == c["message"]
