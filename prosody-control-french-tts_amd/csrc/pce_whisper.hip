@@ -15,8 +15,10 @@
 //   k_logmel_norm    clamp/scale, writes float [80][3000] and the bf16 time-major padded image
 //                    [3002][80] the first convolution reads as an implicit im2col GEMM operand
 //   k_gemm_bf16      C = A B^T on v_mfma_f32_16x16x32_bf16: 128x128x64 tiles, 4 waves x (64x64),
-//                    fp32 accumulate, LDS rows padded to 144 B (conflict-free ds_read_b128),
-//                    fused epilogues (bias, exact GELU, positional add, residual accumulate).
+//                    fp32 accumulate; operands stream global -> LDS with global_load_lds (16 B/lane),
+//                    double buffered behind the MFMAs, XOR-swizzled chunks (conflict-free
+//                    ds_read_b128), XCD-aware tile order, fused epilogues (bias, exact GELU,
+//                    positional add, residual accumulate).
 //                    Both convolutions are this GEMM with overlapping A rows (lda < K): the
 //                    activations are time-major with zero pad rows, so "im2col" is just a stride.
 //   k_layernorm      one wavefront per row, fp32 statistics
@@ -25,6 +27,7 @@
 // The residual stream is fp32, every GEMM operand bf16.  Roofline: MFMA (dense bf16).
 #include "pce_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -155,73 +158,173 @@ __global__ __launch_bounds__(256) void k_logmel_norm(float *__restrict__ logspec
 // GEMM  C[M x N] = A[M x K] * B[N x K]^T  (bf16 in, fp32 accumulate)
 // ---------------------------------------------------------------------------
 enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_GELU_POS_F32 = 2, EPI_RESID_F32 = 3 };
-constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_LD = G_BK + 8;     // LDS row = 72 bf16 = 144 B
+constexpr int G_BM = 128, G_BN = 128, G_BK = 64;
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
-                                                  const bf16 *__restrict__ B, int M, int N, int K,
-                                                  const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
-                                                  const float *__restrict__ pos, int pos_T)
+// GELU(x) = x/2 (1 + erf(x/sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16
+// step of the outputs): libm's erff costs more than the tile's MFMAs in a K = 768 epilogue.
+__device__ __forceinline__ float gelu_exact(float x)
 {
-    __shared__ __attribute__((aligned(16))) bf16 sA[G_BM * G_LD];
-    __shared__ __attribute__((aligned(16))) bf16 sB[G_BN * G_LD];
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    const float erf_x = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf_x);
+}
+
+// LDS image of one operand tile: 128 rows x 64 bf16 (128 B = eight 16-byte chunks per row), rows
+// contiguous (what global_load_lds writes: wave-uniform base + lane * 16 B).  To keep the fragment
+// reads (16 rows x one chunk per ds_read_b128 lane group) conflict-free the chunk index is
+// XOR-swizzled with (row >> 1) & 7: applied to the GLOBAL source address when staging and to the
+// LDS address when reading (the same involution on both sides).
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+constexpr int G_THREADS = 512, G_STAGES = 2;
+constexpr int G_TLD = G_BN + 4;           // fp32 epilogue tile row (pad keeps the accumulator scatter conflict-free)
+
+// one operand tile (128 rows x 64 k): 16 wave-instructions of 1 KiB (8 rows each); 8 waves -> 2 each
+__device__ __forceinline__ void stage_tile(const bf16 *__restrict__ G, int64_t ld, int row0, int row_max, int k0, bf16 *lds_tile, int wv, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r0 = wv * 16 + i * 8;
+        const int row = r0 + (lane >> 3);
+        const int c = swz_chunk(row, lane & 7);
+        int gr = row0 + row; if (gr > row_max) gr = row_max;
+        const bf16 *src = G + (int64_t)gr * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + r0 * G_BK), 16, 0, 0);
+    }
+}
+
+// 8 wavefronts as 2 (M) x 4 (N), each owning a 64 x 32 slice of the 128 x 128 tile.  Three LDS stages:
+// while tile kt is multiplied, tiles kt+1 and kt+2 are in flight as LDS-DMA (4 instructions per wave and
+// tile), so a tile has two full K-steps to arrive.  The barrier is a raw s_barrier behind a COUNTED
+// s_waitcnt vmcnt(4): __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring.
+template <int EPI>
+__global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
+                                                        const bf16 *__restrict__ B, int M, int N, int K,
+                                                        const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
+                                                        const float *__restrict__ pos, int pos_T, int dbg)
+{
+    // operand ring [stage][A|B][128][64] bf16, re-used as the fp32 epilogue tile [128][G_TLD]
+    constexpr int SMEM_ELEMS = (G_STAGES * 2 * G_BM * G_BK * 2 > G_BM * G_TLD * 4 ? G_STAGES * 2 * G_BM * G_BK : G_BM * G_TLD * 2);
+    __shared__ __attribute__((aligned(1024))) bf16 smem[SMEM_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;                     // 2 x 2 waves, each 64 x 64
-    const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+    const int wr = wv >> 2, wc = wv & 3;
+    // XCD-aware tile order: the workgroups that run together on one XCD cover a few M tiles times ALL N
+    // tiles, so every A row block is fetched from HBM once per XCD and re-read from that XCD's L2
+    // (A would otherwise be streamed N/128 times: 10 GB for the QKV projection of a 256-clip batch)
+    const int tiles_n = (int)gridDim.x, tiles_m = (int)gridDim.y;
+    int lin = (int)blockIdx.y * tiles_n + (int)blockIdx.x;
+    const int total = tiles_n * tiles_m;
+    if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    const int m0 = (lin / tiles_n) * G_BM, n0 = (lin % tiles_n) * G_BN;
     A += (int64_t)blockIdx.z * a_batch;
-    f32x4 acc[4][4];
+    f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    for (int k0 = 0; k0 < K; k0 += G_BK) {
-        // stage: 128 rows x 64 k = 1024 16-byte chunks per operand, 4 per thread
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
-            int ar = m0 + row; if (ar >= M) ar = M - 1;
-            const uint4 va = *reinterpret_cast<const uint4 *>(A + (int64_t)ar * lda + k0 + kc);
-            const uint4 vb = *reinterpret_cast<const uint4 *>(B + (int64_t)(n0 + row) * K + k0 + kc);
-            *reinterpret_cast<uint4 *>(&sA[row * G_LD + kc]) = va;
-            *reinterpret_cast<uint4 *>(&sB[row * G_LD + kc]) = vb;
+    const int nk = K / G_BK;
+    constexpr int STAGE = 2 * G_BM * G_BK;
+    stage_tile(A, lda, m0, M - 1, 0, smem, wv, lane);
+    stage_tile(B, K, n0, N - 1, 0, smem + G_BM * G_BK, wv, lane);
+    if (G_STAGES > 2 && nk > 1) {
+        stage_tile(A, lda, m0, M - 1, G_BK, smem + STAGE, wv, lane);
+        stage_tile(B, K, n0, N - 1, G_BK, smem + STAGE + G_BM * G_BK, wv, lane);
+    }
+    for (int kt = 0; kt < ((dbg & 2) ? 1 : nk); kt++) {
+        const bf16 *sA = smem + (kt % G_STAGES) * STAGE, *sB = sA + G_BM * G_BK;
+        // tile kt has landed once at most the 4 youngest DMAs of this wave (tile kt+1) are outstanding
+        if (G_STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + G_STAGES - 1 < nk) {                        // refill the stage tile kt-1 has just released
+            bf16 *nA = smem + ((kt + G_STAGES - 1) % G_STAGES) * STAGE;
+            stage_tile(A, lda, m0, M - 1, (kt + G_STAGES - 1) * G_BK, nA, wv, lane);
+            stage_tile(B, K, n0, N - 1, (kt + G_STAGES - 1) * G_BK, nA + G_BM * G_BK, wv, lane);
         }
-        __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < G_BK; kk += 32) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const bf16x8 *>(&sA[(wr * 64 + i * 16 + fr) * G_LD + kk + fq * 8]);
+            for (int i = 0; i < 4; i++) {
+                const int row = wr * 64 + i * 16 + fr;
+                a[i] = *reinterpret_cast<const bf16x8 *>(&sA[row * G_BK + swz_chunk(row, (kk >> 3) + fq) * 8]);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = *reinterpret_cast<const bf16x8 *>(&sB[(wc * 64 + j * 16 + fr) * G_LD + kk + fq * 8]);
+            for (int j = 0; j < 2; j++) {
+                const int row = wc * 32 + j * 16 + fr;
+                b[j] = *reinterpret_cast<const bf16x8 *>(&sB[row * G_BK + swz_chunk(row, (kk >> 3) + fq) * 8]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
-    // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+    // epilogue.  The accumulator layout (col = lane & 15, row = (lane >> 4) * 4 + reg) would store 2-byte
+    // elements 32 B at a time; measured, such an epilogue cost more than the whole K loop.  The tile
+    // goes through LDS instead (the operand ring is free now) and leaves as full 256-B row segments.
+    __builtin_amdgcn_s_barrier();                           // every wave is done reading the operand stages
+    float *tile = reinterpret_cast<float *>(smem);           // [128][G_TLD] fp32 = 66 KiB
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int col = n0 + wc * 64 + j * 16 + fr;
-            const float bv = bias ? bias[col] : 0.f;
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = m0 + wr * 64 + i * 16 + fq * 4 + r;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                const int64_t o = (int64_t)blockIdx.z * c_batch + (int64_t)row * ldc + col;
-                if (EPI == EPI_BF16) reinterpret_cast<bf16 *>(Cv)[o] = (bf16)v;
-                else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16 *>(Cv)[o] = (bf16)gelu_exact(v);
-                else if (EPI == EPI_GELU_POS_F32) reinterpret_cast<float *>(Cv)[o] = gelu_exact(v) + pos[(int64_t)(row % pos_T) * N + col];
-                else reinterpret_cast<float *>(Cv)[o] += v;
+            for (int r = 0; r < 4; r++)
+                tile[(wr * 64 + i * 16 + fq * 4 + r) * G_TLD + wc * 32 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    if (dbg & 1) return;
+    const int64_t cbase = (int64_t)blockIdx.z * c_batch;
+    if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+        // 16 threads x 8 columns per row, 32 rows per pass
+        const int cx = (tid & 15) * 8, ry = tid >> 4;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) bv[e] = bias ? bias[n0 + cx + e] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int row = ry + 32 * p;
+            if (m0 + row >= M) continue;
+            const float4 v0 = *reinterpret_cast<const float4 *>(&tile[row * G_TLD + cx]);
+            const float4 v1 = *reinterpret_cast<const float4 *>(&tile[row * G_TLD + cx + 4]);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float t = v[e] + bv[e];
+                o[e] = (bf16)(EPI == EPI_GELU_BF16 ? gelu_exact(t) : t);
             }
+            *reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16 *>(Cv) + cbase + (int64_t)(m0 + row) * ldc + n0 + cx) = o;
         }
+    } else {
+        // fp32 outputs: 32 threads x 4 columns per row, 16 rows per pass
+        const int cx = (tid & 31) * 4, ry = tid >> 5;
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) bv[e] = bias ? bias[n0 + cx + e] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int row = ry + 16 * p;
+            if (m0 + row >= M) continue;
+            const float4 v = *reinterpret_cast<const float4 *>(&tile[row * G_TLD + cx]);
+            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(Cv) + cbase + (int64_t)(m0 + row) * ldc + n0 + cx);
+            float4 o;
+            if (EPI == EPI_GELU_POS_F32) {
+                const float4 pe = *reinterpret_cast<const float4 *>(pos + (int64_t)((m0 + row) % pos_T) * N + n0 + cx);
+                o = make_float4(gelu_exact(v.x + bv[0]) + pe.x, gelu_exact(v.y + bv[1]) + pe.y, gelu_exact(v.z + bv[2]) + pe.z,
+                                gelu_exact(v.w + bv[3]) + pe.w);
+            } else {
+                const float4 old = *dst;
+                o = make_float4(old.x + v.x + bv[0], old.y + v.y + bv[1], old.z + v.z + bv[2], old.w + v.w + bv[3]);
+            }
+            *dst = o;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -463,7 +566,8 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
                  void *C, int64_t ldc, int64_t c_batch, int batch, const float *pos = nullptr, int pos_T = 1)
 {
     dim3 grid((unsigned)(N / G_BN), (unsigned)div_up(M, G_BM), (unsigned)batch);
-    hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(256), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T);
+    hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
+                       getenv("PCE_GEMM_DBG") ? atoi(getenv("PCE_GEMM_DBG")) : 0);
 }
 
 } // namespace
