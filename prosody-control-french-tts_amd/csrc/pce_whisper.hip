@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_logmel_norm(float *__restrict__ logspec
 // ---------------------------------------------------------------------------
 // GEMM  C[M x N] = A[M x K] * B[N x K]^T  (bf16 in, fp32 accumulate)
 // ---------------------------------------------------------------------------
-enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_GELU_POS_F32 = 2, EPI_RESID_F32 = 3 };
+enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_GELU_POS_F32 = 2, EPI_RESID_F32 = 3, EPI_QKV = 4 };
+constexpr int AT_SP = 1536;               // padded key axis of the transposed V image (multiple of the 64-key tile)
 constexpr int G_BM = 128, G_BN = 128, G_BK = 64;
 
 // GELU(x) = x/2 (1 + erf(x/sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16
@@ -280,7 +281,30 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
     __syncthreads();
     if (dbg & 1) return;
     const int64_t cbase = (int64_t)blockIdx.z * c_batch;
-    if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
+    if (EPI == EPI_QKV && n0 >= 2 * (N / 3)) {
+        // V columns: written transposed, vt[clip][head][d][key], so the attention kernel can stage V^T tiles
+        // (8 keys contiguous per d) without an LDS transpose.  `pos` carries the vt pointer, pos_T = S.
+        bf16 *vt = reinterpret_cast<bf16 *>(const_cast<float *>(pos));
+        const int dmodel = N / 3, S = pos_T;
+        const int cc = tid & 127, rg = tid >> 7;                  // one column, 8-row groups
+        const int n = n0 + cc - 2 * dmodel, head = n >> 6, dd = n & 63;
+        const float bv = bias ? bias[n0 + cc] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int row = rg * 8 + 32 * p;
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {                      // halves of 4 tokens never straddle a clip (S % 4 == 0)
+                const int m = m0 + row + 4 * hf;
+                if (m >= M) continue;
+                const int clip = m / S, t = m - clip * S;
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (bf16)(tile[(row + 4 * hf + e) * G_TLD + cc] + bv);
+                *reinterpret_cast<bf16x4 *>(vt + (((int64_t)clip * (dmodel >> 6) + head) * 64 + dd) * AT_SP + t) = o;
+            }
+        }
+    } else if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV) {
         // 16 threads x 8 columns per row, 32 rows per pass
         const int cx = (tid & 15) * 8, ry = tid >> 4;
         float bv[8];
@@ -330,6 +354,20 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
 // ---------------------------------------------------------------------------
 // LayerNorm over the last dimension (one wavefront per row)
 // ---------------------------------------------------------------------------
+// The row (d <= 1280 floats) is read once with 16-byte loads and kept in registers (<= 5 float4 per lane);
+// statistics in fp32, two-pass (mean, then centred second moment) as torch does.
+template <class OUT> __device__ __forceinline__ void ln_store4(OUT *p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void ln_store4<float>(float *p, float a, float b, float c, float d)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void ln_store4<bf16>(bf16 *p, float a, float b, float c, float d)
+{
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 v; v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
+    *reinterpret_cast<bf16x4 *>(p) = v;
+}
+
 template <class OUT>
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
                                                   int64_t rows, int d, OUT *__restrict__ out)
@@ -337,136 +375,180 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float *xr = x + row * d;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + row * d);
+    const int nv = d >> 2;                               // float4 per row, d % 4 == 0
+    float4 v[5];
     float s = 0.f;
-    for (int i = lane; i < d; i += 64) s += xr[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float mean = s / (float)d;
     float q = 0.f;
-    for (int i = lane; i < d; i += 64) { const float t = xr[i] - mean; q += t * t; }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (lane + 64 * i < nv) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
     const float inv = rsqrtf(q / (float)d + 1e-5f);
-    for (int i = lane; i < d; i += 64) out[row * d + i] = (OUT)((xr[i] - mean) * inv * w[i] + b[i]);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 ww = reinterpret_cast<const float4 *>(w)[idx], bb = reinterpret_cast<const float4 *>(b)[idx];
+            ln_store4<OUT>(out + row * d + 4 * idx, (v[i].x - mean) * inv * ww.x + bb.x, (v[i].y - mean) * inv * ww.y + bb.y,
+                           (v[i].z - mean) * inv * ww.z + bb.z, (v[i].w - mean) * inv * ww.w + bb.w);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
-// attention forward: softmax(Q K^T / sqrt(64)) V for one (clip, head, 64 queries)
+// attention forward, transposed formulation on v_mfma_f32_32x32x16_bf16.
+//   S^T = K Q^T   (keys on the accumulator rows, queries on its columns = lanes)
+//   O^T = V^T P^T (P^T is consumed straight out of the S^T accumulator registers as the B operand:
+//                  a 32x32 result has its column on the lane and its rows in the 16 registers, which is
+//                  exactly a B fragment summed over the row index; no LDS round trip, no cross-lane
+//                  softmax reductions except one exchange between the two lane halves)
+// The S^T accumulator row rho of lane-half h, register 4g+i is rho = i + 8g + 4h.  The k-step s of the
+// second product reads registers 8s..8s+7, i.e. rows 16s + 8a + 4h + b (j = 4a + b).  Softmax does not
+// care about the order of the keys inside a tile, so lane r loads K row pi(r) (pi swaps bits 2 and 3):
+// then slot (h, j) of k-step s is key 16s + 8h + j and the V^T fragment is one contiguous 16-byte read.
+// One workgroup = 4 waves x 32 queries of one (clip, head); K [64 keys][64 d] and V^T [64 d][64 keys]
+// tiles stream through LDS by DMA (global_load_lds), double buffered, XOR-swizzled like the GEMM operands.
 // ---------------------------------------------------------------------------
-constexpr int AT_LD = 72;
-template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int AT_QB = 128;                  // queries per workgroup
+
+__device__ __forceinline__ void stage_kv(const bf16 *__restrict__ kbase, int64_t kld, int key0, int key_max,
+                                         const bf16 *__restrict__ vtbase, bf16 *sK, bf16 *sVt, int wv, int lane)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row_max16(float v)
-{
-    v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ float row_sum16f(float v)
-{
-    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
-    return v;
+    // K tile: 64 rows (keys) x 128 B; V^T tile: 64 rows (d) x 128 B; 8 wave-instructions each, 2 per wave
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r0 = wv * 16 + i * 8, row = r0 + (lane >> 3);
+        const int c = swz_chunk(row, lane & 7);
+        int kr = key0 + row; if (kr > key_max) kr = key_max;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kbase + (int64_t)kr * kld + c * 8),
+                                         (__attribute__((address_space(3))) void *)(sK + r0 * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vtbase + (int64_t)row * AT_SP + key0 + c * 8),
+                                         (__attribute__((address_space(3))) void *)(sVt + r0 * 64), 16, 0, 0);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qkv /* [clips*S][3 d] */, int S, int d_model,
-                                                  bf16 *__restrict__ out /* [clips*S][d] */)
+__global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qk /* [clips*S][2 d]: q | k */, const bf16 *__restrict__ vt,
+                                                  int S, int d_model, bf16 *__restrict__ out /* [clips*S][d] */)
 {
-    __shared__ __attribute__((aligned(16))) bf16 sK[64 * AT_LD];         // [key][d]
-    __shared__ __attribute__((aligned(16))) bf16 sVt[64 * AT_LD];        // [d][key]
-    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * AT_LD];      // per wave [query][key]
+    __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * 64 * 64];        // [stage][K | V^T][64][64] = 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int head = blockIdx.y, clip = blockIdx.z, q0 = blockIdx.x * 64;
-    const int64_t ld = 3 * (int64_t)d_model;
-    const bf16 *base = qkv + (int64_t)clip * S * ld + head * 64;
-    // Q fragments (A operand): row = query fr of this wave's 16, k = d
-    bf16x8 qf[2];
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, clip = blockIdx.z, q0 = blockIdx.x * AT_QB + wv * 32;
+    const int H = d_model >> 6;
+    const int64_t ld = 2 * (int64_t)d_model;
+    const bf16 *qbase = qk + (int64_t)clip * S * ld + head * 64;
+    const bf16 *kbase = qbase + d_model;
+    const bf16 *vtbase = vt + ((int64_t)clip * H + head) * 64 * AT_SP;
+    // Q^T fragments (B operand): lane holds Q[q r][16 s + 8 h + j]
+    bf16x8 qf[4];
     {
-        int qr = q0 + wv * 16 + fr; if (qr >= S) qr = S - 1;
-        const bf16 *qp = base + (int64_t)qr * ld;
-        qf[0] = *reinterpret_cast<const bf16x8 *>(qp + fq * 8);
-        qf[1] = *reinterpret_cast<const bf16x8 *>(qp + 32 + fq * 8);
+        int qr = q0 + r; if (qr >= S) qr = S - 1;
+        const bf16 *qp = qbase + (int64_t)qr * ld;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) qf[s4] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s4 + 8 * h);
     }
-    f32x4 o[4];
+    f32x16 o[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[4], l_run[4];
+    for (int t = 0; t < 2; t++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) { m_run[r] = -1e30f; l_run[r] = 0.f; }
-    const float scale = 0.125f;                                        // (64^-0.25)^2
-    for (int k0 = 0; k0 < S; k0 += 64) {
-        __syncthreads();
-        // stage K [key][d] and V^T [d][key]: 64 x 64 each = 512 16-byte chunks, 2 per thread
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int c = tid + 256 * i, key = c >> 3, dc = (c & 7) * 8;
-            int kr = k0 + key; if (kr >= S) kr = S - 1;
-            const bf16 *kp = base + (int64_t)kr * ld + d_model + dc;
-            *reinterpret_cast<uint4 *>(&sK[key * AT_LD + dc]) = *reinterpret_cast<const uint4 *>(kp);
-            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(kp + d_model);
-#pragma unroll
-            for (int e = 0; e < 8; e++) sVt[(dc + e) * AT_LD + key] = v[e];
+        for (int e = 0; e < 16; e++) o[t][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float sl2 = 0.125f * 1.4426950408889634f;               // softmax scale * log2(e): exp(x) = exp2(x log2 e)
+    const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): swap bits 2 and 3
+    const int nt = (S + 63) / 64;
+    stage_kv(kbase, ld, 0, S - 1, vtbase, smem, smem + 64 * 64, wv, lane);
+    for (int kt = 0; kt < nt; kt++) {
+        const bf16 *sK = smem + (kt & 1) * (2 * 64 * 64), *sVt = sK + 64 * 64;
+        __syncthreads();                                          // tile kt landed (vmcnt(0)), tile kt-1 consumed
+        if (kt + 1 < nt) {
+            bf16 *nK = smem + ((kt + 1) & 1) * (2 * 64 * 64);
+            stage_kv(kbase, ld, (kt + 1) * 64, S - 1, vtbase, nK, nK + 64 * 64, wv, lane);
         }
-        __syncthreads();
-        // S = Q K^T : 16 queries x 64 keys per wave
-        f32x4 sc[4];
+        // S^T for the two 32-key halves of the tile
+        f32x16 st[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 2; u++) {
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(&sK[(j * 16 + fr) * AT_LD + kk * 32 + fq * 8]);
-                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, sc[j], 0, 0, 0);
+            for (int e = 0; e < 16; e++) st[u][e] = 0.f;
+            const int row = u * 32 + pr;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(&sK[row * 64 + swz_chunk(row, 2 * s4 + h) * 8]);
+                st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s4], st[u], 0, 0, 0);
             }
         }
-        // online softmax; this lane holds rows fq*4 + r, column fr of each of the 4 key groups
-        float p[4][4];
+        // online softmax over this lane's query column: rows (keys) live in the registers of the two lane halves
+        float mx = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float mx = -1e30f;
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool valid = (k0 + j * 16 + fr) < S;
-                const float v = valid ? sc[j][r] * scale : -1e30f;
-                p[j][r] = v; mx = fmaxf(mx, v);
+            for (int e = 0; e < 16; e++) {
+                const int rho = (e & 3) + 8 * (e >> 2) + 4 * h;                       // accumulator row
+                const int key = kt * 64 + u * 32 + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
+                const float v = key < S ? st[u][e] * sl2 : -1e30f;
+                st[u][e] = v; mx = fmaxf(mx, v);
             }
-            mx = row_max16(mx);
-            const float m_new = fmaxf(m_run[r], mx);
-            const float corr = __expf(m_run[r] - m_new);
-            float sum = 0.f;
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float corr = exp2f(m_run - m_new);
+        float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const float e = __expf(p[j][r] - m_new); p[j][r] = e; sum += e; }
-            sum = row_sum16f(sum);
-            l_run[r] = l_run[r] * corr + sum;
-            m_run[r] = m_new;
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) o[j][r] *= corr;
-        }
-        // P -> LDS (row-major [query][key]) -> A fragments
+            for (int e = 0; e < 16; e++) { const float pe = exp2f(st[u][e] - m_new); st[u][e] = pe; sum += pe; }
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * corr + sum;
+        m_run = m_new;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) sP[wv][(fq * 4 + r) * AT_LD + j * 16 + fr] = (bf16)p[j][r];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < 16; e++) o[t][e] *= corr;
+        // O^T += V^T P^T : k-step (u, s2) covers keys u*32 + 16 s2 .. +15 (in pi order); B = registers 8 s2 .. 8 s2 + 7
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            const bf16x8 pf = *reinterpret_cast<const bf16x8 *>(&sP[wv][fr * AT_LD + kk * 32 + fq * 8]);
+        for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(&sVt[(j * 16 + fr) * AT_LD + kk * 32 + fq * 8]);
-                o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[j], 0, 0, 0);
+            for (int s2 = 0; s2 < 2; s2++) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) pf[j] = (bf16)st[u][8 * s2 + j];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int row = t * 32 + r;                                           // d
+                    const int chunk = (u * 32 + 16 * s2 + 8 * h) >> 3;                    // keys u*32+16 s2+8h .. +7
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(&sVt[row * 64 + swz_chunk(row, chunk) * 8]);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+                }
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int qr = q0 + wv * 16 + fq * 4 + r;
-        if (qr >= S) continue;
-        const float inv = 1.0f / l_run[r];
+    // O^T[d][q]: this lane owns query q0 + r; d = 32 t + (e & 3) + 8 (e >> 2) + 4 h -> runs of 4 consecutive d
+    const int qr = q0 + r;
+    if (qr < S) {
+        const float inv = 1.0f / l_run;
         bf16 *op = out + ((int64_t)clip * S + qr) * d_model + head * 64;
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
-        for (int j = 0; j < 4; j++) op[j * 16 + fr] = (bf16)(o[j][r] * inv);
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                bf16x4 v4;
+#pragma unroll
+                for (int i = 0; i < 4; i++) v4[i] = (bf16)(o[t][4 * g + i] * inv);
+                *reinterpret_cast<bf16x4 *>(op + 32 * t + 8 * g + 4 * h) = v4;
+            }
     }
 }
 
@@ -502,7 +584,8 @@ struct WhisperState {
     pce_whisper_dims dims{};
     bool loaded = false;
     DevBuf tables, logspec, clipmax, mel_tm, w_bf16, w_f32, pos;
-    DevBuf c1_out, resid, ln_out, qkv, attn, hidden, final_out;
+    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out;
+    size_t vt_elems_zeroed = 0;
     MelTables mt{};
     int mel_nmels = 0;
     int32_t n_clips_mel = -1, n_clips_enc = -1;
@@ -577,7 +660,7 @@ void pce_whisper_free(pce_ctx *c)
     if (!c->whisper) return;
     WhisperState *w = static_cast<WhisperState *>(c->whisper);
     DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
-                      &w->ln_out, &w->qkv, &w->attn, &w->hidden, &w->final_out};
+                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->hidden, &w->final_out};
     for (auto b : bufs) b->release();
     delete w;
     c->whisper = nullptr;
@@ -725,7 +808,16 @@ int pce_whisper_encode_run(pce_ctx *c)
     PCE_HIP(c, w->c1_out.reserve(sizeof(bf16) * c1_elems));
     PCE_HIP(c, w->resid.reserve(sizeof(float) * (size_t)M * d));
     PCE_HIP(c, w->ln_out.reserve(sizeof(bf16) * (size_t)M * d));
-    PCE_HIP(c, w->qkv.reserve(sizeof(bf16) * (size_t)M * 3 * d));
+    PCE_HIP(c, w->qkv.reserve(sizeof(bf16) * (size_t)M * 2 * d));            // q | k, row-major
+    const size_t vt_elems = (size_t)n * (size_t)d * AT_SP + 64;          // V^T [clip][head][64][AT_SP], pad keys stay zero
+    {
+        const size_t before = w->vt.cap;
+        PCE_HIP(c, w->vt.reserve(sizeof(bf16) * vt_elems));
+        if (w->vt.cap != before || w->vt_elems_zeroed < vt_elems) {
+            PCE_HIP(c, hipMemsetAsync(w->vt.p, 0, sizeof(bf16) * vt_elems, c->stream));
+            w->vt_elems_zeroed = vt_elems;
+        }
+    }
     PCE_HIP(c, w->attn.reserve(sizeof(bf16) * (size_t)M * d));
     PCE_HIP(c, w->hidden.reserve(sizeof(bf16) * (size_t)M * 4 * d));
     PCE_HIP(c, w->final_out.reserve(sizeof(float) * (size_t)M * d));
@@ -743,9 +835,11 @@ int pce_whisper_encode_run(pce_ctx *c)
         const WhisperState::Layer &ly = w->layers[(size_t)l];
         hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln1_w,
                            Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
-        launch_gemm<EPI_BF16>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 3 * d, 0, 1);
-        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, 64), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream,
-                           w->qkv.as<bf16>(), W_CTX, d, w->attn.as<bf16>());
+        // Q | K go to the row-major [M][2d] buffer, V is written transposed per head (pos carries the pointer)
+        launch_gemm<EPI_QKV>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 2 * d, 0, 1,
+                             reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX);
+        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream,
+                           w->qkv.as<bf16>(), w->vt.as<bf16>(), W_CTX, d, w->attn.as<bf16>());
         launch_gemm<EPI_RESID_F32>(c, w->attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, w->resid.as<float>(), d, 0, 1);
         hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln2_w,
                            Wf + ly.ln2_b, M, d, w->ln_out.as<bf16>());
