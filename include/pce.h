@@ -84,6 +84,16 @@ int pce_upload_pcm_s16(pce_ctx *ctx, const int16_t *pcm, const int64_t *offsets,
 int pce_bind_pcm_s16_device(pce_ctx *ctx, const void *d_pcm, const int64_t *offsets, int32_t n_clips, int32_t sample_rate);
 int pce_num_clips(const pce_ctx *ctx);
 
+/* ---- sample-rate conversion of the resident batch -------
+ * Stands in for the ffmpeg decode-to-16-kHz inside whisper.load_audio
+ * (Code/Aligners/use_whisper_timestamped.py:139): y = upfirdn(taps, x, up, down)[n_pre_remove : n_pre_remove + n_out],
+ * n_out = ceil(n_in * up / down), fp64 accumulation, round-half-even to int16.  The low-pass
+ * `taps` (already scaled by `up`, zero padded as scipy.signal.resample_poly does) is host logic
+ * (hostrules.resample_filter).  The resampled batch REPLACES the resident batch. */
+int pce_resample_run(pce_ctx *ctx, int32_t up, int32_t down, const double *taps, int32_t n_taps, int64_t n_pre_remove);
+/* copy the resident batch back: pcm may be NULL to query offsets[n_clips+1] / sample_rate only */
+int pce_download_pcm_s16(pce_ctx *ctx, int16_t *pcm, int64_t *offsets, int32_t *sample_rate);
+
 /* ---- R3 / R7: short-time energy, peak, silence gate --------------------
  * Replaces _calculate_loudness (Code/Pipeline/compute_loudness_adjustments.py:8-25),
  * _check_audio_content (Code/Aligners/use_whisper_timestamped.py:197-229 and its
@@ -192,7 +202,7 @@ enum pce_kernel_id {
     PCE_K_ENERGY = 0,
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
-    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC,
+    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE,
     PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);

@@ -393,3 +393,15 @@ def stft_db(y_f32: np.ndarray, n_fft=1024, hop=256, amin=1e-5, top_db=80.0) -> n
     log_spec = 10.0 * np.log10(np.maximum(np.float32(amin * amin), power))
     log_spec -= 10.0 * np.log10(np.maximum(np.float32(amin * amin), np.float32(ref) ** 2))
     return np.maximum(log_spec, log_spec.max() - top_db).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# sample-rate conversion spec (ffmpeg's resampler is not reproducible here)
+# --------------------------------------------------------------------------
+def resample_int16(pcm_i16: np.ndarray, rate_in: int, rate_out: int) -> np.ndarray:
+    """The engine's resampling spec stated with scipy: resample_poly (Kaiser 5.0 low-pass, zero
+    padding), round half to even, saturate to int16."""
+    import scipy.signal
+    g = math.gcd(rate_in, rate_out)
+    y = scipy.signal.resample_poly(np.asarray(pcm_i16, dtype=np.float64), rate_out // g, rate_in // g)
+    return np.clip(np.rint(y), -32768, 32767).astype(np.int16)

@@ -77,7 +77,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -85,6 +85,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_energy_run", "pce_energy_fetch", "pce_lufs_run", "pce_lufs_fetch",
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
+           "pce_resample_run", "pce_download_pcm_s16",
            "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
@@ -115,6 +116,8 @@ def load_library() -> C.CDLL:
     lib.pce_stft_db_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_stft_db_fetch.argtypes = [vp, i32, vp]
     lib.pce_stft_db_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    lib.pce_resample_run.argtypes = [vp, i32, i32, vp, i32, i64]
+    lib.pce_download_pcm_s16.argtypes = [vp, vp, vp, C.POINTER(i32)]
     lib.pce_logmel_run.argtypes = [vp, i32]
     lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
@@ -283,6 +286,26 @@ class ProsodyEngine:
         p = C.c_void_p(); n = C.c_int64()
         self._check(self._lib.pce_stft_db_device(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    # ---------------------------------------------------------------- sample-rate conversion
+    def resample(self, target_rate: int):
+        """Resample the resident batch to ``target_rate`` (polyphase, scipy.signal.resample_poly's filter design)."""
+        from .hostrules import resample_filter
+        if target_rate == self.rate:
+            return self
+        up, down, taps, n_pre_remove = resample_filter(self.rate, target_rate)
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self._check(self._lib.pce_resample_run(self._ctx, up, down, taps.ctypes.data, len(taps), n_pre_remove))
+        off = np.zeros(len(self.clip_lengths) + 1, dtype=np.int64); rate = C.c_int32()
+        self._check(self._lib.pce_download_pcm_s16(self._ctx, None, off.ctypes.data, C.byref(rate)))
+        self.rate, self.offsets, self.clip_lengths = rate.value, off, np.diff(off)
+        return self
+
+    def download(self):
+        """The resident batch as a list of int16 arrays."""
+        pcm = np.zeros(max(int(self.offsets[-1]), 1), dtype=np.int16)
+        self._check(self._lib.pce_download_pcm_s16(self._ctx, pcm.ctypes.data, None, None))
+        return [pcm[self.offsets[i]:self.offsets[i + 1]].copy() for i in range(len(self.clip_lengths))]
 
     # ---------------------------------------------------------------- whisper front end
     def logmel_run(self, n_mels: int = 80):

@@ -122,3 +122,29 @@ def gate_from_counts(sum_sq: int, n_loud: int, n: int):
     ratio = 1.0 - (n_loud / n) if n else float("nan")
     ok = not (ratio > 0.95 or rms < 100)
     return rms, ratio, ok
+
+
+# ---------------------------------------------------------------- resampling filter (host-side design)
+def resample_filter(rate_in: int, rate_out: int, beta: float = 5.0):
+    """Low-pass of ``scipy.signal.resample_poly(x, up, down)`` (window ('kaiser', 5.0)): returns
+    (up, down, taps, n_pre_remove) with ``taps`` scaled by ``up`` and zero padded exactly as scipy does,
+    so that y = upfirdn(taps, x, up, down)[n_pre_remove : n_pre_remove + ceil(n * up / down)]."""
+    g = math.gcd(int(rate_in), int(rate_out))
+    up, down = int(rate_out) // g, int(rate_in) // g
+    max_rate = max(up, down)
+    f_c = 1.0 / max_rate
+    half_len = 10 * max_rate
+    numtaps = 2 * half_len + 1
+    m = np.arange(numtaps) - (numtaps - 1) / 2.0
+    h = f_c * np.sinc(f_c * m)                                   # firwin: ideal low-pass, cutoff f_c (Nyquist = 1)
+    n = np.arange(numtaps)
+    alpha = (numtaps - 1) / 2.0
+    w = np.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - ((n - alpha) / alpha) ** 2))) / np.i0(beta)
+    h = h * w
+    h = h / np.sum(h)                                            # unit DC gain
+    h = h * up
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+    # scipy adds post padding until the filtered length covers n_out + n_pre_remove; harmless extra zeros here
+    taps = np.concatenate([np.zeros(n_pre_pad), h, np.zeros(down)])
+    return up, down, taps, int(n_pre_remove)

@@ -201,3 +201,30 @@ def test_legacy_pipeline_modules_on_gpu(engine, excerpts, tmp_path):
     res = AL.check_audio_content_batch([str(tmp_path / c["file"]) for c in gate])
     for c, (ok, msg) in zip(gate, res):
         assert ok == c["ok"] and msg == c["message"]
+
+
+def test_resampler_and_whisper_front_end_on_demo_audio(engine, excerpts):
+    """44.1 kHz demo recordings -> 16 kHz on the GPU (the ffmpeg step of whisper.load_audio, with the
+    engine's own polyphase spec) -> log-mel.  The resampler must reproduce the scipy statement of the spec
+    sample for sample (<= 1 LSB on rounding ties), the log-mel the torch restatement."""
+    from oracle import whisper_oracle as WO
+    rate, clips = excerpts
+    names = sorted(clips)[:5]
+    src = [clips[n] for n in names] + [np.zeros(1, dtype=np.int16), np.full(4410, 12000, dtype=np.int16)]
+    engine.upload(src, rate)
+    engine.resample(16000)
+    assert engine.rate == 16000
+    got = engine.download()
+    for x, y in zip(src, got):
+        want = O.resample_int16(x, rate, 16000)
+        assert len(y) == len(want) == -(-len(x) * 160 // 441)
+        d = np.abs(y.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-4
+    engine.logmel_run(80)
+    for i in range(len(names)):
+        assert np.max(np.abs(engine.logmel_fetch(i) - WO.log_mel(got[i], 80))) <= 2e-3
+    # the resampled batch is a normal resident batch: pitch on it matches the oracle on the same samples
+    res = engine.pitch(engine.whole_clip_slices(), E.PitchParams.praat(150.0, 600.0))
+    f = res["f0"][res["frame_offsets"][0]:res["frame_offsets"][1]]
+    want = O.pitch_ac(got[0] / 32768.0, 1 / 16000, 0.5 / 16000, O.praat_params(150.0, 600.0))["f0"]
+    assert np.array_equal(f > 0, want > 0) and np.max(np.abs(f[want > 0] - want[want > 0]) / want[want > 0]) <= 1e-6
