@@ -195,6 +195,14 @@ int pce_whisper_load(pce_ctx *ctx, const pce_whisper_dims *dims, const float *we
 int pce_whisper_encode_run(pce_ctx *ctx);
 int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
 
+/* ---- R8: dynamic time warping (alignment indices) ------------------------
+ * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on
+ * (Code/Aligners/use_whisper_timestamped.py:163): x is `batch` row-major [n_rows][n_cols] fp64 cost matrices
+ * (tokens x frames, n_rows <= 1024); path_i / path_j receive up to n_rows + n_cols index pairs per matrix
+ * (stride n_rows + n_cols), path_len their count.  Indices are bit-identical to the CPU recurrence. */
+int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32_t batch, int32_t *path_i, int32_t *path_j,
+            int32_t *path_len);
+
 /* ---- measurement -------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; pce_profile_get returns the accumulated device time. */
@@ -202,7 +210,7 @@ enum pce_kernel_id {
     PCE_K_ENERGY = 0,
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
-    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE,
+    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW,
     PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);

@@ -87,3 +87,37 @@ def encoder_forward(mel: np.ndarray, W: dict, dims: dict) -> np.ndarray:
         x = x + h
     x = F.layer_norm(x, (d,), t(W["ln_post.weight"]), t(W["ln_post.bias"]))
     return x[0].numpy()
+
+
+def dtw_path(x: np.ndarray):
+    """openai-whisper timing.py ``dtw_cpu`` + ``backtrace`` (numba there, plain numpy loops here)."""
+    x = np.asarray(x, dtype=np.float64)
+    N, M = x.shape
+    cost = np.ones((N + 1, M + 1), dtype=np.float64) * np.inf
+    trace = -np.ones((N + 1, M + 1), dtype=np.int64)
+    cost[0, 0] = 0
+    for j in range(1, M + 1):
+        for i in range(1, N + 1):
+            c0, c1, c2 = cost[i - 1, j - 1], cost[i - 1, j], cost[i, j - 1]
+            if c0 < c1 and c0 < c2:
+                c, t = c0, 0
+            elif c1 < c0 and c1 < c2:
+                c, t = c1, 1
+            else:
+                c, t = c2, 2
+            cost[i, j] = x[i - 1, j - 1] + c
+            trace[i, j] = t
+    i, j = N, M
+    trace[0, :] = 2
+    trace[:, 0] = 1
+    out = []
+    while i > 0 or j > 0:
+        out.append((i - 1, j - 1))
+        if trace[i, j] == 0:
+            i -= 1; j -= 1
+        elif trace[i, j] == 1:
+            i -= 1
+        else:
+            j -= 1
+    out = np.array(out)[::-1]
+    return out[:, 0], out[:, 1]

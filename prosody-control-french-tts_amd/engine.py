@@ -77,7 +77,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -86,7 +86,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
+           "pce_dtw", "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
 
@@ -118,6 +118,7 @@ def load_library() -> C.CDLL:
     lib.pce_stft_db_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.pce_resample_run.argtypes = [vp, i32, i32, vp, i32, i64]
     lib.pce_download_pcm_s16.argtypes = [vp, vp, vp, C.POINTER(i32)]
+    lib.pce_dtw.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.pce_logmel_run.argtypes = [vp, i32]
     lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
@@ -330,6 +331,16 @@ class ProsodyEngine:
         out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)
         self._check(self._lib.pce_whisper_encode_fetch(self._ctx, int(clip), out.ctypes.data))
         return out
+
+    def dtw(self, cost: np.ndarray):
+        """DTW paths of a batch of [n_rows, n_cols] fp64 cost matrices -> list of (text_indices, time_indices)."""
+        x = np.ascontiguousarray(cost, dtype=np.float64)
+        if x.ndim == 2:
+            x = x[None]
+        b, n, m = x.shape
+        pi = np.zeros((b, n + m), dtype=np.int32); pj = np.zeros((b, n + m), dtype=np.int32); pl = np.zeros(b, dtype=np.int32)
+        self._check(self._lib.pce_dtw(self._ctx, x.ctypes.data, n, m, b, pi.ctypes.data, pj.ctypes.data, pl.ctypes.data))
+        return [(pi[k, :pl[k]].copy(), pj[k, :pl[k]].copy()) for k in range(b)]
 
     # ---------------------------------------------------------------- measurement
     def profile_enable(self, on=True):

@@ -51,3 +51,26 @@ def test_encoder_matches_torch(engine, clips, dims):
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
         assert rel <= 2e-2, rel
         assert np.max(np.abs(got - want)) <= 6e-2 * max(1.0, float(np.std(want)))
+
+
+def test_dtw_indices_bit_exact(engine):
+    """Alignment indices: the GPU wavefront DTW returns exactly the path of the CPU recurrence."""
+    rng = np.random.default_rng(9)
+    mats = []
+    for (n, m) in [(1, 1), (1, 40), (37, 1), (5, 7), (64, 200)]:
+        mats.append(rng.standard_normal((n, m)))
+    # ties everywhere (integer costs) and a hand-computable diagonal
+    mats.append(rng.integers(0, 3, size=(20, 55)).astype(np.float64))
+    mats.append(-np.eye(12, 12))
+    for x in mats:
+        (gi, gj), = engine.dtw(x)
+        wi, wj = WO.dtw_path(x)
+        assert np.array_equal(gi, wi) and np.array_equal(gj, wj), x.shape
+    # batch of Whisper-sized matrices (tokens x 1500 frames), attention-like costs
+    t = np.linspace(0, 1, 1500)[None, :]
+    centers = np.sort(rng.uniform(0, 1, size=(3, 90, 1)), axis=1)
+    cost = -np.exp(-0.5 * ((t - centers) / 0.02) ** 2) + 0.05 * rng.standard_normal((3, 90, 1500))
+    for x, (gi, gj) in zip(cost, engine.dtw(cost)):
+        wi, wj = WO.dtw_path(x)
+        assert np.array_equal(gi, wi) and np.array_equal(gj, wj)
+        assert gi[0] == 0 and gj[0] == 0 and gi[-1] == 89 and gj[-1] == 1499 and np.all(np.diff(gi) >= 0) and np.all(np.diff(gj) >= 0)
