@@ -206,7 +206,7 @@ template <int EPI>
 __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
                                                         const bf16 *__restrict__ B, int M, int N, int K,
                                                         const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
-                                                        const float *__restrict__ pos, int pos_T, int dbg)
+                                                        const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp)
 {
     // operand ring [stage][A|B][128][64] bf16, re-used as the fp32 epilogue tile [128][G_TLD]
     constexpr int SMEM_ELEMS = (G_STAGES * 2 * G_BM * G_BK * 2 > G_BM * G_TLD * 4 ? G_STAGES * 2 * G_BM * G_BK : G_BM * G_TLD * 2);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
         stage_tile(A, lda, m0, M - 1, G_BK, smem + STAGE, wv, lane);
         stage_tile(B, K, n0, N - 1, G_BK, smem + STAGE + G_BM * G_BK, wv, lane);
     }
-    for (int kt = 0; kt < ((dbg & 2) ? 1 : nk); kt++) {
+    for (int kt = 0; kt < nk; kt++) {
         const bf16 *sA = smem + (kt % G_STAGES) * STAGE, *sB = sA + G_BM * G_BK;
         // tile kt has landed once at most the 4 youngest DMAs of this wave (tile kt+1) are outstanding
         if (G_STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -279,15 +279,14 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
             for (int r = 0; r < 4; r++)
                 tile[(wr * 64 + i * 16 + fq * 4 + r) * G_TLD + wc * 32 + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
-    if (dbg & 1) return;
     const int64_t cbase = (int64_t)blockIdx.z * c_batch;
-    if (EPI == EPI_QKV && n0 >= 2 * (N / 3)) {
+    if (EPI == EPI_QKV && n0 >= v_col0) {
         // V columns: written transposed, vt[clip][head][d][key], so the attention kernel can stage V^T tiles
         // (8 keys contiguous per d) without an LDS transpose.  `pos` carries the vt pointer, pos_T = S.
         bf16 *vt = reinterpret_cast<bf16 *>(const_cast<float *>(pos));
-        const int dmodel = N / 3, S = pos_T;
+        const int dmodel = N - v_col0, S = pos_T;                   // V is the last d_model columns
         const int cc = tid & 127, rg = tid >> 7;                  // one column, 8-row groups
-        const int n = n0 + cc - 2 * dmodel, head = n >> 6, dd = n & 63;
+        const int n = n0 + cc - v_col0, head = n >> 6, dd = n & 63;
         const float bv = bias ? bias[n0 + cc] : 0.f;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; e++) o[e] = (bf16)(tile[(row + 4 * hf + e) * G_TLD + cc] + bv);
-                *reinterpret_cast<bf16x4 *>(vt + (((int64_t)clip * (dmodel >> 6) + head) * 64 + dd) * AT_SP + t) = o;
+                *reinterpret_cast<bf16x4 *>(vt + (((int64_t)clip * (dmodel >> 6) + head) * 64 + dd) * vt_sp + t) = o;
             }
         }
     } else if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV) {
@@ -425,8 +424,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int AT_QB = 128;                  // queries per workgroup
 
+struct AttnArgs {
+    const bf16 *q; int64_t q_ld;            // query row i of clip c: q + (q_row0[c] + i) * q_ld + head * 64
+    const bf16 *k; int64_t k_ld;            // key row j:             k + (k_row0[c] + j) * k_ld + head * 64
+    const bf16 *vt; int64_t vt_clip; int vt_sp;   // V^T: vt + c * vt_clip + (head * 64 + d) * vt_sp + j
+    const int *q_row0, *q_len, *k_row0, *k_len;   // per clip
+    bf16 *out; int64_t out_ld;              // out + (q_row0[c] + i) * out_ld + head * 64
+    int causal;                             // key j visible to query i only if j <= i
+};
+
 __device__ __forceinline__ void stage_kv(const bf16 *__restrict__ kbase, int64_t kld, int key0, int key_max,
-                                         const bf16 *__restrict__ vtbase, bf16 *sK, bf16 *sVt, int wv, int lane)
+                                         const bf16 *__restrict__ vtbase, int vt_sp, bf16 *sK, bf16 *sVt, int wv, int lane)
 {
     // K tile: 64 rows (keys) x 128 B; V^T tile: 64 rows (d) x 128 B; 8 wave-instructions each, 2 per wave
 #pragma unroll
@@ -436,28 +444,28 @@ __device__ __forceinline__ void stage_kv(const bf16 *__restrict__ kbase, int64_t
         int kr = key0 + row; if (kr > key_max) kr = key_max;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kbase + (int64_t)kr * kld + c * 8),
                                          (__attribute__((address_space(3))) void *)(sK + r0 * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vtbase + (int64_t)row * AT_SP + key0 + c * 8),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vtbase + (int64_t)row * vt_sp + key0 + c * 8),
                                          (__attribute__((address_space(3))) void *)(sVt + r0 * 64), 16, 0, 0);
     }
 }
 
-__global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qk /* [clips*S][2 d]: q | k */, const bf16 *__restrict__ vt,
-                                                  int S, int d_model, bf16 *__restrict__ out /* [clips*S][d] */)
+__global__ __launch_bounds__(256) void k_attention(AttnArgs A)
 {
     __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * 64 * 64];        // [stage][K | V^T][64][64] = 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, clip = blockIdx.z, q0 = blockIdx.x * AT_QB + wv * 32;
-    const int H = d_model >> 6;
-    const int64_t ld = 2 * (int64_t)d_model;
-    const bf16 *qbase = qk + (int64_t)clip * S * ld + head * 64;
-    const bf16 *kbase = qbase + d_model;
-    const bf16 *vtbase = vt + ((int64_t)clip * H + head) * 64 * AT_SP;
+    const int head = blockIdx.y, clip = blockIdx.z;
+    const int Sq = A.q_len[clip], Sk = A.k_len[clip];
+    if ((int)blockIdx.x * AT_QB >= Sq) return;
+    const int q0 = blockIdx.x * AT_QB + wv * 32;
+    const bf16 *qbase = A.q + (int64_t)A.q_row0[clip] * A.q_ld + head * 64;
+    const bf16 *kbase = A.k + (int64_t)A.k_row0[clip] * A.k_ld + head * 64;
+    const bf16 *vtbase = A.vt + (int64_t)clip * A.vt_clip + (int64_t)head * 64 * A.vt_sp;
     // Q^T fragments (B operand): lane holds Q[q r][16 s + 8 h + j]
     bf16x8 qf[4];
     {
-        int qr = q0 + r; if (qr >= S) qr = S - 1;
-        const bf16 *qp = qbase + (int64_t)qr * ld;
+        int qr = q0 + r; if (qr >= Sq) qr = Sq - 1;
+        const bf16 *qp = qbase + (int64_t)qr * A.q_ld;
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) qf[s4] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s4 + 8 * h);
     }
@@ -469,14 +477,17 @@ __global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qk /
     float m_run = -1e30f, l_run = 0.f;
     const float sl2 = 0.125f * 1.4426950408889634f;               // softmax scale * log2(e): exp(x) = exp2(x log2 e)
     const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): swap bits 2 and 3
-    const int nt = (S + 63) / 64;
-    stage_kv(kbase, ld, 0, S - 1, vtbase, smem, smem + 64 * 64, wv, lane);
+    int k_need = Sk;
+    if (A.causal) k_need = min(Sk, (int)blockIdx.x * AT_QB + AT_QB);               // keys beyond the block's last query are masked
+    const int nt = (k_need + 63) / 64;
+    const int my_q = q0 + r;
+    stage_kv(kbase, A.k_ld, 0, Sk - 1, vtbase, A.vt_sp, smem, smem + 64 * 64, wv, lane);
     for (int kt = 0; kt < nt; kt++) {
         const bf16 *sK = smem + (kt & 1) * (2 * 64 * 64), *sVt = sK + 64 * 64;
         __syncthreads();                                          // tile kt landed (vmcnt(0)), tile kt-1 consumed
         if (kt + 1 < nt) {
             bf16 *nK = smem + ((kt + 1) & 1) * (2 * 64 * 64);
-            stage_kv(kbase, ld, (kt + 1) * 64, S - 1, vtbase, nK, nK + 64 * 64, wv, lane);
+            stage_kv(kbase, A.k_ld, (kt + 1) * 64, Sk - 1, vtbase, A.vt_sp, nK, nK + 64 * 64, wv, lane);
         }
         // S^T for the two 32-key halves of the tile
         f32x16 st[2];
@@ -499,7 +510,8 @@ __global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qk /
             for (int e = 0; e < 16; e++) {
                 const int rho = (e & 3) + 8 * (e >> 2) + 4 * h;                       // accumulator row
                 const int key = kt * 64 + u * 32 + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
-                const float v = key < S ? st[u][e] * sl2 : -1e30f;
+                const bool vis = key < Sk && (!A.causal || key <= my_q);
+                const float v = vis ? st[u][e] * sl2 : -1e30f;
                 st[u][e] = v; mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -509,7 +521,10 @@ __global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qk /
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) { const float pe = exp2f(st[u][e] - m_new); st[u][e] = pe; sum += pe; }
+            for (int e = 0; e < 16; e++) {
+                const float pe = st[u][e] > -1e29f ? exp2f(st[u][e] - m_new) : 0.f;    // a fully masked tile must add nothing
+                st[u][e] = pe; sum += pe;
+            }
         sum += __shfl_xor(sum, 32, 64);
         l_run = l_run * corr + sum;
         m_run = m_new;
@@ -535,10 +550,9 @@ __global__ __launch_bounds__(256) void k_attention(const bf16 *__restrict__ qk /
             }
     }
     // O^T[d][q]: this lane owns query q0 + r; d = 32 t + (e & 3) + 8 (e >> 2) + 4 h -> runs of 4 consecutive d
-    const int qr = q0 + r;
-    if (qr < S) {
+    if (my_q < Sq) {
         const float inv = 1.0f / l_run;
-        bf16 *op = out + ((int64_t)clip * S + qr) * d_model + head * 64;
+        bf16 *op = A.out + ((int64_t)A.q_row0[clip] + my_q) * A.out_ld + head * 64;
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -584,7 +598,7 @@ struct WhisperState {
     pce_whisper_dims dims{};
     bool loaded = false;
     DevBuf tables, logspec, clipmax, mel_tm, w_bf16, w_f32, pos;
-    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out;
+    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab;
     size_t vt_elems_zeroed = 0;
     MelTables mt{};
     int mel_nmels = 0;
@@ -646,11 +660,12 @@ int mel_setup(pce_ctx *c, WhisperState *w, int n_mels)
 
 template <int EPI>
 void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const bf16 *B, int M, int N, int K, const float *bias,
-                 void *C, int64_t ldc, int64_t c_batch, int batch, const float *pos = nullptr, int pos_T = 1)
+                 void *C, int64_t ldc, int64_t c_batch, int batch, const float *pos = nullptr, int pos_T = 1, int v_col0 = 0,
+                 int vt_sp = AT_SP)
 {
     dim3 grid((unsigned)(N / G_BN), (unsigned)div_up(M, G_BM), (unsigned)batch);
     hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
-                       getenv("PCE_GEMM_DBG") ? atoi(getenv("PCE_GEMM_DBG")) : 0);
+                       v_col0, vt_sp);
 }
 
 } // namespace
@@ -660,7 +675,7 @@ void pce_whisper_free(pce_ctx *c)
     if (!c->whisper) return;
     WhisperState *w = static_cast<WhisperState *>(c->whisper);
     DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
-                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->hidden, &w->final_out};
+                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->hidden, &w->final_out};
     for (auto b : bufs) b->release();
     delete w;
     c->whisper = nullptr;
@@ -823,6 +838,13 @@ int pce_whisper_encode_run(pce_ctx *c)
     PCE_HIP(c, w->final_out.reserve(sizeof(float) * (size_t)M * d));
     const bf16 *Wb = w->w_bf16.as<bf16>();
     const float *Wf = w->w_f32.as<float>();
+    {   // per-clip row tables of the attention descriptor: clip c owns rows [1500 c, 1500 c + 1500)
+        std::vector<int> tab((size_t)2 * n);
+        for (int i = 0; i < n; i++) { tab[(size_t)i] = i * W_CTX; tab[(size_t)n + i] = W_CTX; }
+        PCE_HIP(c, w->enc_tab.reserve(sizeof(int) * tab.size()));
+        PCE_HIP(c, hipMemcpyAsync(w->enc_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipStreamSynchronize(c->stream));
+    }
     KernelTimer t(c, PCE_K_WHISPER_ENC);
     PCE_HIP(c, hipMemsetAsync(w->c1_out.p, 0, sizeof(bf16) * c1_elems, c->stream));
     // conv1: per clip, A row t starts at padded row t (= t-1 unpadded), K = 3 n_mels (padded to K1p with zero weights)
@@ -837,9 +859,15 @@ int pce_whisper_encode_run(pce_ctx *c)
                            Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
         // Q | K go to the row-major [M][2d] buffer, V is written transposed per head (pos carries the pointer)
         launch_gemm<EPI_QKV>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 2 * d, 0, 1,
-                             reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX);
-        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream,
-                           w->qkv.as<bf16>(), w->vt.as<bf16>(), W_CTX, d, w->attn.as<bf16>());
+                             reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX, 2 * d, AT_SP);
+        {
+            AttnArgs a{};
+            a.q = w->qkv.as<bf16>(); a.q_ld = 2 * d; a.k = w->qkv.as<bf16>() + d; a.k_ld = 2 * d;
+            a.vt = w->vt.as<bf16>(); a.vt_clip = (int64_t)d * AT_SP; a.vt_sp = AT_SP;
+            a.q_row0 = a.k_row0 = w->enc_tab.as<int>(); a.q_len = a.k_len = w->enc_tab.as<int>() + n;
+            a.out = w->attn.as<bf16>(); a.out_ld = d; a.causal = 0;
+            hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+        }
         launch_gemm<EPI_RESID_F32>(c, w->attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, w->resid.as<float>(), d, 0, 1);
         hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln2_w,
                            Wf + ly.ln2_b, M, d, w->ln_out.as<bf16>());
