@@ -195,6 +195,30 @@ int pce_whisper_load(pce_ctx *ctx, const pce_whisper_dims *dims, const float *we
 int pce_whisper_encode_run(pce_ctx *ctx);
 int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
 
+/* ---- R8: forced alignment of known text tokens (teacher-forced decoder + cross-attention DTW) ----
+ * openai-whisper timing.py find_alignment, the mechanism whisper_timestamped's word timestamps rest on
+ * (Code/Aligners/use_whisper_timestamped.py:163): TextDecoder.forward over the given token sequence
+ * (sot sequence, no-timestamps, text tokens, eot), cross-attention logits of the alignment heads ->
+ * softmax over the first num_frames/2 audio positions -> std/mean normalisation over tokens -> median filter
+ * over time -> mean over heads -> DTW of -matrix[sot_len:-1].  Token ids -> words is tokenizer (host) logic.
+ * Needs pce_whisper_encode_run on the same batch.  Decoder weight blob (float32, PyTorch layouts):
+ *   token_embedding[n_vocab][d] positional_embedding[n_text_ctx][d]
+ *   per layer: attn_ln.w,b  attn.{query.w,query.b,key.w,value.w,value.b,out.w,out.b}
+ *              cross_attn_ln.w,b  cross_attn.{query.w,query.b,key.w,value.w,value.b,out.w,out.b}
+ *              mlp_ln.w,b  mlp.0.w,b  mlp.2.w,b
+ *   ln.w,b */
+typedef struct pce_whisper_text_dims {
+    int32_t n_vocab, n_text_ctx /* <= 448 */, n_state, n_head, n_layer;
+} pce_whisper_text_dims;
+int pce_whisper_decoder_load(pce_ctx *ctx, const pce_whisper_text_dims *dims, const float *weights, int64_t n_floats);
+/* tokens: concatenated per clip (token_offsets[n_clips+1]); num_frames: mel frames of real audio per clip;
+ * head_mask: [n_layer * n_head] bytes or NULL (all heads of the last half of the layers, whisper's default) */
+int pce_whisper_align_run(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets, const int32_t *num_frames,
+                          int32_t sot_len, const uint8_t *head_mask, int32_t medfilt_width, float qk_scale);
+int pce_whisper_align_shape(pce_ctx *ctx, int32_t clip, int32_t *n_rows, int32_t *n_cols);
+/* path arrays hold up to n_rows + n_cols entries; cost (nullable) is the [n_rows][n_cols] fp64 DTW input */
+int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32_t *time_idx, int32_t *path_len, double *cost);
+
 /* ---- R8: dynamic time warping (alignment indices) ------------------------
  * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on
  * (Code/Aligners/use_whisper_timestamped.py:163): x is `batch` row-major [n_rows][n_cols] fp64 cost matrices
@@ -210,7 +234,7 @@ enum pce_kernel_id {
     PCE_K_ENERGY = 0,
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
-    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW,
+    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN,
     PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);

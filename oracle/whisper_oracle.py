@@ -121,3 +121,68 @@ def dtw_path(x: np.ndarray):
             j -= 1
     out = np.array(out)[::-1]
     return out[:, 0], out[:, 1]
+
+
+def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
+    """openai-whisper timing.py median_filter (reflect padding along the last axis)."""
+    pad = width // 2
+    if x.shape[-1] <= pad:
+        return x
+    x = F.pad(x[None], (pad, pad, 0, 0), mode="reflect")[0] if x.ndim == 3 else F.pad(x, (pad, pad, 0, 0), mode="reflect")
+    return x.unfold(-1, width, 1).sort()[0][..., width // 2]
+
+
+def find_alignment(tokens, enc_out: np.ndarray, W: dict, dims: dict, num_frames: int, sot_len: int, head_mask=None,
+                   medfilt_width: int = 7, qk_scale: float = 1.0):
+    """TextDecoder.forward (teacher forced) + the cross-attention / DTW part of timing.py find_alignment.
+    Returns (cost matrix fed to the DTW, text_indices, time_indices)."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    d, H, L = dims["n_state"], dims["n_head"], dims["n_layer"]
+    tok = torch.tensor(tokens, dtype=torch.long)
+    T = len(tokens)
+    xa = t(enc_out)[None]
+    x = t(W["token_embedding.weight"])[tok][None] + t(W["positional_embedding"])[:T]
+    mask = torch.empty(T, T).fill_(-np.inf).triu_(1)
+    if head_mask is None:
+        head_mask = np.zeros((L, H), dtype=bool); head_mask[L // 2:] = True
+    head_mask = np.asarray(head_mask, dtype=bool).reshape(L, H)
+    qks = []
+
+    def mha(xq, xkv, p, m):
+        q = F.linear(xq, t(W[p + "query.weight"]), t(W[p + "query.bias"]))
+        k = F.linear(xkv, t(W[p + "key.weight"]))
+        v = F.linear(xkv, t(W[p + "value.weight"]), t(W[p + "value.bias"]))
+        n_b, n_q, _ = q.shape
+        scale = (d // H) ** -0.25
+        qh = q.view(n_b, n_q, H, -1).permute(0, 2, 1, 3) * scale
+        kh = k.view(n_b, k.shape[1], H, -1).permute(0, 2, 3, 1) * scale
+        vh = v.view(n_b, v.shape[1], H, -1).permute(0, 2, 1, 3)
+        qk = qh @ kh
+        if m is not None:
+            qk = qk + m
+        w = F.softmax(qk.float(), dim=-1)
+        out = (w @ vh).permute(0, 2, 1, 3).flatten(start_dim=2)
+        return F.linear(out, t(W[p + "out.weight"]), t(W[p + "out.bias"])), qk[0]
+
+    for l in range(L):
+        p = f"blocks.{l}."
+        a, _ = mha(F.layer_norm(x, (d,), t(W[p + "attn_ln.weight"]), t(W[p + "attn_ln.bias"])), None if False else
+                   F.layer_norm(x, (d,), t(W[p + "attn_ln.weight"]), t(W[p + "attn_ln.bias"])), p + "attn.", mask)
+        x = x + a
+        a, qk = mha(F.layer_norm(x, (d,), t(W[p + "cross_attn_ln.weight"]), t(W[p + "cross_attn_ln.bias"])), xa, p + "cross_attn.", None)
+        x = x + a
+        for hh in range(H):
+            if head_mask[l, hh]:
+                qks.append(qk[hh])
+        h = F.layer_norm(x, (d,), t(W[p + "mlp_ln.weight"]), t(W[p + "mlp_ln.bias"]))
+        x = x + F.linear(F.gelu(F.linear(h, t(W[p + "mlp.0.weight"]), t(W[p + "mlp.0.bias"]))), t(W[p + "mlp.2.weight"]), t(W[p + "mlp.2.bias"]))
+    weights = torch.stack(qks)[:, :, : num_frames // 2]
+    weights = (weights * qk_scale).softmax(dim=-1)
+    std, mean = torch.std_mean(weights, dim=-2, keepdim=True, unbiased=False)
+    weights = (weights - mean) / std
+    weights = median_filter(weights, medfilt_width)
+    matrix = weights.mean(axis=0)
+    matrix = matrix[sot_len:-1]
+    cost = (-matrix).double().numpy()
+    ti, tj = dtw_path(cost)
+    return cost, ti, tj

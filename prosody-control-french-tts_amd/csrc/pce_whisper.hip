@@ -566,6 +566,158 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs A)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Text decoder (teacher forced) and cross-attention alignment  -- openai-whisper timing.py find_alignment
+// ---------------------------------------------------------------------------
+__global__ void k_embed_tokens(const int *__restrict__ tokens /* [clips][T_pad] */, const float *__restrict__ tok_emb,
+                               const float *__restrict__ pos_emb, int T_pad, int n_ctx, int d, int64_t rows, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * d) return;
+    const int64_t m = i / d; const int col = (int)(i - m * d);
+    int t = (int)(m % T_pad); if (t >= n_ctx) t = n_ctx - 1;      // pad rows beyond the clip's tokens: any finite value
+    out[i] = tok_emb[(int64_t)tokens[m] * d + col] + pos_emb[(int64_t)t * d + col];
+}
+
+// softmax over the audio frames of the (scaled) cross-attention logits of one alignment head:
+// w[clip][sel][t][s] = softmax_s(q_t . k_s * 0.125 * qk_scale), s < F_c.  16 tokens per workgroup, 4 waves x 16
+// keys per 64-key tile on v_mfma_f32_16x16x32_bf16, two passes (row max / sum, then normalised write).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_max16(float v)      // over the 16 lanes of a DPP row, result in every lane
+{
+    v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float row_sum16f(float v)
+{
+    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
+    return v;
+}
+struct AlignArgs {
+    const bf16 *q; int64_t q_ld;             // decoder cross-attention queries [clips * T_pad][d]
+    const bf16 *k; int64_t k_ld;             // audio keys of this layer      [clips * 1500][d]
+    const int *t_len, *f_len;                // per clip: tokens, frames considered (num_frames // 2)
+    const int *heads;                        // head index of every selected head of this layer
+    float *w; int sel0, n_sel_total, T_pad, F_pad;
+    float scale;
+};
+__global__ __launch_bounds__(256) void k_align_scores(AlignArgs A)
+{
+    __shared__ float red_m[4][16], red_s[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int clip = blockIdx.z, sel = blockIdx.y, t0 = blockIdx.x * 16;
+    const int T = A.t_len[clip], F = A.f_len[clip];
+    if (t0 >= T || F <= 0) return;
+    const int head = A.heads[sel];
+    const bf16 *qb = A.q + ((int64_t)clip * A.T_pad) * A.q_ld + head * 64;
+    const bf16 *kb = A.k + ((int64_t)clip * W_CTX) * A.k_ld + head * 64;
+    bf16x8 qf[2];
+    {
+        int tr = t0 + fr; if (tr >= T) tr = T - 1;
+        qf[0] = *reinterpret_cast<const bf16x8 *>(qb + (int64_t)tr * A.q_ld + fq * 8);
+        qf[1] = *reinterpret_cast<const bf16x8 *>(qb + (int64_t)tr * A.q_ld + 32 + fq * 8);
+    }
+    float *wb = A.w + (((int64_t)clip * A.n_sel_total + A.sel0 + sel) * A.T_pad) * (int64_t)A.F_pad;
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) { m_run[r4] = -1e30f; l_run[r4] = 0.f; }
+    for (int pass = 0; pass < 2; pass++) {
+        for (int s0 = wv * 16; s0 < F; s0 += 64) {
+            int kr = s0 + fr; if (kr >= F) kr = F - 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)kr * A.k_ld + kk * 32 + fq * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, acc, 0, 0, 0);
+            }
+            const bool valid = (s0 + fr) < F;                  // column = key s0 + fr, rows = tokens fq*4 + r4
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const float v = valid ? acc[r4] * A.scale : -1e30f;
+                if (pass == 0) {
+                    const float mx = row_max16(v);
+                    const float m_new = fmaxf(m_run[r4], mx);
+                    const float e = valid ? __expf(v - m_new) : 0.f;
+                    l_run[r4] = l_run[r4] * __expf(m_run[r4] - m_new) + row_sum16f(e);
+                    m_run[r4] = m_new;
+                } else if (valid && t0 + fq * 4 + r4 < T) {
+                    wb[(int64_t)(t0 + fq * 4 + r4) * A.F_pad + s0 + fr] = __expf(v - m_run[r4]) / l_run[r4];
+                }
+            }
+        }
+        if (pass == 0) {                                       // merge the four waves' partial (max, sum) per token row
+            if (fr == 0)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) { red_m[wv][fq * 4 + r4] = m_run[r4]; red_s[wv][fq * 4 + r4] = l_run[r4]; }
+            __syncthreads();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const int row = fq * 4 + r4;
+                float m = fmaxf(fmaxf(red_m[0][row], red_m[1][row]), fmaxf(red_m[2][row], red_m[3][row]));
+                float l = 0.f;
+                for (int u = 0; u < 4; u++) l += red_s[u][row] * __expf(red_m[u][row] - m);
+                m_run[r4] = m; l_run[r4] = l;
+            }
+        }
+    }
+}
+
+// std/mean normalisation over the token axis (torch.std_mean(dim=-2, unbiased=False)), in place
+__global__ __launch_bounds__(256) void k_align_colnorm(float *__restrict__ w, const int *__restrict__ t_len, const int *__restrict__ f_len,
+                                                      int n_sel, int T_pad, int F_pad)
+{
+    const int clip = blockIdx.z, sel = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = t_len[clip], F = f_len[clip];
+    if (s >= F) return;
+    float *col = w + (((int64_t)clip * n_sel + sel) * T_pad) * (int64_t)F_pad + s;
+    float sum = 0.f;
+    for (int t = 0; t < T; t++) sum += col[(int64_t)t * F_pad];
+    const float mean = sum / (float)T;
+    float q = 0.f;
+    for (int t = 0; t < T; t++) { const float a = col[(int64_t)t * F_pad] - mean; q += a * a; }
+    const float sd = sqrtf(q / (float)T);
+    for (int t = 0; t < T; t++) col[(int64_t)t * F_pad] = (col[(int64_t)t * F_pad] - mean) / sd;
+}
+
+// median filter along time (reflect padding), mean over the selected heads, rows [sot_len, T-1) -> cost = -mean (fp64)
+__global__ __launch_bounds__(256) void k_align_cost(const float *__restrict__ w, const int *__restrict__ t_len, const int *__restrict__ f_len,
+                                                   int n_sel, int T_pad, int F_pad, int sot_len, int width, int N_max,
+                                                   double *__restrict__ cost /* [clips][N_max][F_pad] */)
+{
+    const int clip = blockIdx.z, row = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = t_len[clip], F = f_len[clip];
+    const int t = row + sot_len;
+    if (t >= T - 1 || s >= F) return;
+    const int pad = width / 2;
+    float acc = 0.f;
+    for (int sel = 0; sel < n_sel; sel++) {
+        const float *rp = w + ((((int64_t)clip * n_sel + sel) * T_pad) + t) * (int64_t)F_pad;
+        float v;
+        if (F <= pad) v = rp[s];                               // torch skips the filter for very short rows
+        else {
+            float win[15];
+            for (int u = 0; u < width; u++) {
+                int idx = s - pad + u;
+                if (idx < 0) idx = -idx;
+                if (idx >= F) idx = 2 * (F - 1) - idx;
+                win[u] = rp[idx];
+            }
+            for (int a = 1; a < width; a++) {                  // insertion sort of <= 15 values
+                const float key = win[a]; int b = a - 1;
+                while (b >= 0 && win[b] > key) { win[b + 1] = win[b]; b--; }
+                win[b + 1] = key;
+            }
+            v = win[pad];
+        }
+        acc += v;
+    }
+    cost[((int64_t)clip * N_max + row) * F_pad + s] = -(double)(acc / (float)n_sel);
+}
+
 __global__ void k_f32_to_bf16(const float *__restrict__ in, bf16 *__restrict__ out, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,6 +752,17 @@ struct WhisperState {
     DevBuf tables, logspec, clipmax, mel_tm, w_bf16, w_f32, pos;
     DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab;
     size_t vt_elems_zeroed = 0;
+    // text decoder
+    pce_whisper_text_dims tdims{};
+    bool dec_loaded = false;
+    DevBuf dw_bf16, dw_f32, d_tok_emb, d_pos_emb;
+    DevBuf d_tab, d_tokens, d_resid, d_ln, d_qk, d_vt, d_attn, d_q, d_hidden, d_enc_bf16, d_aw, d_cost, d_trace, d_pi, d_pj, d_pl, d_heads;
+    struct DLayer { size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, lnx_w, lnx_b, xq_w, xq_b, xkv_w, xkv_b, xout_w, xout_b,
+                    ln2_w, ln2_b, m1_w, m1_b, m2_w, m2_b; };
+    std::vector<DLayer> dlayers;
+    size_t dln_w = 0, dln_b = 0;
+    int al_n = -1, al_Nmax = 0, al_Fpad = 0, al_Mmax = 0;
+    std::vector<int> al_rows, al_cols;
     MelTables mt{};
     int mel_nmels = 0;
     int32_t n_clips_mel = -1, n_clips_enc = -1;
@@ -675,7 +838,9 @@ void pce_whisper_free(pce_ctx *c)
     if (!c->whisper) return;
     WhisperState *w = static_cast<WhisperState *>(c->whisper);
     DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
-                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->hidden, &w->final_out};
+                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
+                      &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
+                      &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out};
     for (auto b : bufs) b->release();
     delete w;
     c->whisper = nullptr;
@@ -891,6 +1056,241 @@ int pce_whisper_encode_fetch(pce_ctx *c, int32_t clip, float *out)
     PCE_HIP(c, hipMemcpyAsync(out, w->final_out.as<float>() + per * (size_t)clip, sizeof(float) * per, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
+    return PCE_OK;
+}
+
+} // extern "C"
+
+int pce_dtw_launch(pce_ctx *c, const double *d_x, int64_t x_stride, int ld, const int *d_rows, const int *d_cols, int N_max, int M_max,
+                   int batch, unsigned char *d_trace, int *d_pi, int *d_pj, int *d_pl);
+
+extern "C" {
+
+int pce_whisper_decoder_load(pce_ctx *c, const pce_whisper_text_dims *dims, const float *weights, int64_t n_floats)
+{
+    if (!c || !dims || !weights) return PCE_E_INVALID;
+    const int d = dims->n_state, L = dims->n_layer, V = dims->n_vocab, TC = dims->n_text_ctx;
+    if (d <= 0 || d % 128 || dims->n_head * 64 != d || L <= 0 || V <= 0 || TC <= 0 || TC > 448)
+        return pce_fail(c, PCE_E_LIMIT, "unsupported decoder dims (need n_state %% 128 == 0, head size 64, n_text_ctx <= 448)");
+    const int64_t per_layer = 2LL * d + (4LL * d * d + 3LL * d) + 2LL * d + (4LL * d * d + 3LL * d) + 2LL * d + 8LL * d * d + 5LL * d;
+    const int64_t expect = (int64_t)V * d + (int64_t)TC * d + L * per_layer + 2LL * d;
+    if (n_floats != expect) return pce_fail(c, PCE_E_INVALID, "decoder weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)expect);
+    PCE_HIP(c, hipSetDevice(c->device));
+    WhisperState *w = ws_of(c);
+    w->tdims = *dims; w->dec_loaded = false; w->dlayers.assign((size_t)L, {});
+    std::vector<float> mats, vecs;
+    auto add_vec = [&](const float *p, size_t n) { size_t o = vecs.size(); vecs.insert(vecs.end(), p, p + n); return o; };
+    auto add_zero = [&](size_t n) { size_t o = vecs.size(); vecs.insert(vecs.end(), n, 0.f); return o; };
+    auto add_mat = [&](const float *p, size_t n) { size_t o = mats.size(); mats.insert(mats.end(), p, p + n); return o; };
+    const float *p = weights;
+    const float *tok = p; p += (size_t)V * d;
+    const float *pos = p; p += (size_t)TC * d;
+    const size_t dd = (size_t)d * d;
+    for (int l = 0; l < L; l++) {
+        WhisperState::DLayer &ly = w->dlayers[(size_t)l];
+        ly.ln1_w = add_vec(p, (size_t)d); p += d; ly.ln1_b = add_vec(p, (size_t)d); p += d;
+        {   // self attention: q.w q.b k.w v.w v.b out.w out.b -> fused [3d][d]
+            const float *qw = p, *qb = qw + dd, *kw = qb + d, *vw = kw + dd, *vb = vw + dd;
+            ly.qkv_w = add_mat(qw, dd); add_mat(kw, dd); add_mat(vw, dd);
+            ly.qkv_b = add_vec(qb, (size_t)d); add_zero((size_t)d); add_vec(vb, (size_t)d);
+            p = vb + d;
+            ly.out_w = add_mat(p, dd); p += dd; ly.out_b = add_vec(p, (size_t)d); p += d;
+        }
+        ly.lnx_w = add_vec(p, (size_t)d); p += d; ly.lnx_b = add_vec(p, (size_t)d); p += d;
+        {   // cross attention: q from text, k | v from audio -> [d][d] and fused [2d][d]
+            const float *qw = p, *qb = qw + dd, *kw = qb + d, *vw = kw + dd, *vb = vw + dd;
+            ly.xq_w = add_mat(qw, dd); ly.xq_b = add_vec(qb, (size_t)d);
+            ly.xkv_w = add_mat(kw, dd); add_mat(vw, dd);
+            ly.xkv_b = add_zero((size_t)d); add_vec(vb, (size_t)d);
+            p = vb + d;
+            ly.xout_w = add_mat(p, dd); p += dd; ly.xout_b = add_vec(p, (size_t)d); p += d;
+        }
+        ly.ln2_w = add_vec(p, (size_t)d); p += d; ly.ln2_b = add_vec(p, (size_t)d); p += d;
+        ly.m1_w = add_mat(p, 4 * dd); p += 4 * dd; ly.m1_b = add_vec(p, (size_t)4 * d); p += 4 * d;
+        ly.m2_w = add_mat(p, 4 * dd); p += 4 * dd; ly.m2_b = add_vec(p, (size_t)d); p += d;
+    }
+    w->dln_w = add_vec(p, (size_t)d); p += d; w->dln_b = add_vec(p, (size_t)d); p += d;
+    DevBuf tmp;
+    PCE_HIP(c, tmp.reserve(sizeof(float) * mats.size()));
+    PCE_HIP(c, w->dw_bf16.reserve(sizeof(bf16) * mats.size() + 256));
+    PCE_HIP(c, w->dw_f32.reserve(sizeof(float) * vecs.size()));
+    PCE_HIP(c, w->d_tok_emb.reserve(sizeof(float) * (size_t)V * d));
+    PCE_HIP(c, w->d_pos_emb.reserve(sizeof(float) * (size_t)TC * d));
+    PCE_HIP(c, hipMemcpyAsync(tmp.p, mats.data(), sizeof(float) * mats.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->dw_f32.p, vecs.data(), sizeof(float) * vecs.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->d_tok_emb.p, tok, sizeof(float) * (size_t)V * d, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->d_pos_emb.p, pos, sizeof(float) * (size_t)TC * d, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up((int64_t)mats.size(), 256)), dim3(256), 0, c->stream, tmp.as<float>(),
+                       w->dw_bf16.as<bf16>(), (int64_t)mats.size());
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    w->dec_loaded = true;
+    return PCE_OK;
+}
+
+int pce_whisper_align_run(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, const int32_t *num_frames, int32_t sot_len,
+                          const uint8_t *head_mask, int32_t medfilt_width, float qk_scale)
+{
+    if (!c || !tokens || !token_offsets || !num_frames) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (!w->dec_loaded) return pce_fail(c, PCE_E_STATE, "pce_whisper_align_run before pce_whisper_decoder_load");
+    if (w->n_clips_enc < 0) return pce_fail(c, PCE_E_STATE, "run pce_whisper_encode_run first");
+    if (w->tdims.n_state != w->dims.n_state) return pce_fail(c, PCE_E_INVALID, "decoder and encoder widths differ");
+    if (medfilt_width < 1 || medfilt_width > 15 || !(medfilt_width & 1)) return pce_fail(c, PCE_E_INVALID, "median filter width must be odd, <= 15");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int n = w->n_clips_enc, d = w->tdims.n_state, H = w->tdims.n_head, L = w->tdims.n_layer, V = w->tdims.n_vocab;
+    // ---- shapes
+    int T_max = 0, F_max = 0, N_max = 0;
+    std::vector<int> t_len((size_t)n), f_len((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const int T = token_offsets[i + 1] - token_offsets[i];
+        if (T < sot_len + 2 || T > w->tdims.n_text_ctx) return pce_fail(c, PCE_E_INVALID, "clip %d: %d tokens (need %d..%d)", i, T, sot_len + 2, w->tdims.n_text_ctx);
+        int F = num_frames[i] / 2; if (F > W_CTX) F = W_CTX; if (F < 1) return pce_fail(c, PCE_E_INVALID, "clip %d: no audio frames", i);
+        t_len[(size_t)i] = T; f_len[(size_t)i] = F;
+        T_max = std::max(T_max, T); F_max = std::max(F_max, F); N_max = std::max(N_max, T - sot_len - 1);
+    }
+    const int T_pad = (int)div_up(T_max, 64) * 64, F_pad = (int)div_up(F_max, 64) * 64, SPD = 512;
+    const int64_t Mt = (int64_t)n * T_pad, Ma = (int64_t)n * W_CTX;
+    // selected heads (default: every head of the last half of the layers, as whisper's Whisper.__init__ sets alignment_heads)
+    std::vector<int> heads; std::vector<int> layer_first((size_t)L + 1, 0);
+    for (int l = 0; l < L; l++) {
+        layer_first[(size_t)l] = (int)heads.size();
+        for (int hh = 0; hh < H; hh++)
+            if (head_mask ? head_mask[l * H + hh] != 0 : l >= L / 2) heads.push_back(hh);
+    }
+    layer_first[(size_t)L] = (int)heads.size();
+    const int n_sel = (int)heads.size();
+    if (n_sel == 0) return pce_fail(c, PCE_E_INVALID, "no alignment head selected");
+    // ---- tables: [q_row0 | q_len | a_row0 | a_len | f_len | n_rows(dtw)] and padded tokens
+    std::vector<int> tab((size_t)6 * n), tok((size_t)Mt, 0);
+    for (int i = 0; i < n; i++) {
+        tab[(size_t)i] = i * T_pad; tab[(size_t)n + i] = t_len[(size_t)i]; tab[(size_t)2 * n + i] = i * W_CTX; tab[(size_t)3 * n + i] = W_CTX;
+        tab[(size_t)4 * n + i] = f_len[(size_t)i]; tab[(size_t)5 * n + i] = t_len[(size_t)i] - sot_len - 1;
+        for (int t = 0; t < t_len[(size_t)i]; t++) {
+            const int v = tokens[token_offsets[i] + t];
+            if (v < 0 || v >= V) return pce_fail(c, PCE_E_INVALID, "token %d out of the vocabulary", v);
+            tok[(size_t)i * T_pad + t] = v;
+        }
+    }
+    w->al_rows.assign(tab.begin() + 5 * n, tab.begin() + 6 * n); w->al_cols = f_len;
+    PCE_HIP(c, w->d_tab.reserve(sizeof(int) * tab.size()));
+    PCE_HIP(c, w->d_tokens.reserve(sizeof(int) * tok.size()));
+    PCE_HIP(c, w->d_heads.reserve(sizeof(int) * heads.size()));
+    PCE_HIP(c, hipMemcpyAsync(w->d_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->d_tokens.p, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->d_heads.p, heads.data(), sizeof(int) * heads.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    const int *T0 = w->d_tab.as<int>(), *TL = T0 + n, *A0 = T0 + 2 * n, *AL = T0 + 3 * n, *FL = T0 + 4 * n, *NR = T0 + 5 * n;
+    // ---- buffers
+    PCE_HIP(c, w->d_resid.reserve(sizeof(float) * (size_t)Mt * d));
+    PCE_HIP(c, w->d_ln.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    PCE_HIP(c, w->d_qk.reserve(sizeof(bf16) * (size_t)Mt * 2 * d + 4096));
+    PCE_HIP(c, w->d_attn.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    PCE_HIP(c, w->d_q.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    PCE_HIP(c, w->d_hidden.reserve(sizeof(bf16) * (size_t)Mt * 4 * d + 4096));
+    PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)Ma * d + 4096));
+    const size_t dvt_elems = (size_t)n * (size_t)d * SPD + 64;
+    PCE_HIP(c, w->d_vt.reserve(sizeof(bf16) * dvt_elems));
+    PCE_HIP(c, hipMemsetAsync(w->d_vt.p, 0, sizeof(bf16) * dvt_elems, c->stream));
+    PCE_HIP(c, w->d_aw.reserve(sizeof(float) * (size_t)n * n_sel * T_pad * (size_t)F_pad));
+    PCE_HIP(c, w->d_cost.reserve(sizeof(double) * (size_t)n * N_max * (size_t)F_pad));
+    PCE_HIP(c, w->d_trace.reserve((size_t)n * (size_t)(N_max + 1) * (size_t)(F_max + 1)));
+    PCE_HIP(c, w->d_pi.reserve(sizeof(int) * (size_t)n * (size_t)(N_max + F_max)));
+    PCE_HIP(c, w->d_pj.reserve(sizeof(int) * (size_t)n * (size_t)(N_max + F_max)));
+    PCE_HIP(c, w->d_pl.reserve(sizeof(int) * (size_t)n));
+    // the audio keys/values reuse the encoder's q|k and V^T buffers (the encoder is finished)
+    bf16 *xk = w->qkv.as<bf16>(), *xvt = w->vt.as<bf16>();
+    const bf16 *Wb = w->dw_bf16.as<bf16>();
+    const float *Wf = w->dw_f32.as<float>();
+    KernelTimer timer(c, PCE_K_WHISPER_ALIGN);
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up(Ma * d, 256)), dim3(256), 0, c->stream, w->final_out.as<float>(),
+                       w->d_enc_bf16.as<bf16>(), Ma * d);
+    hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)div_up(Mt * d, 256)), dim3(256), 0, c->stream, w->d_tokens.as<int>(),
+                       w->d_tok_emb.as<float>(), w->d_pos_emb.as<float>(), T_pad, w->tdims.n_text_ctx, d, Mt, w->d_resid.as<float>());
+    auto attn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp,
+                    const int *k0, const int *kl, int causal) {
+        AttnArgs a{};
+        a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
+        a.q_row0 = T0; a.q_len = TL; a.k_row0 = k0; a.k_len = kl; a.out = w->d_attn.as<bf16>(); a.out_ld = d; a.causal = causal;
+        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+    };
+    for (int l = 0; l < L; l++) {
+        const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
+        // masked self attention
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(Mt, 4)), dim3(256), 0, c->stream, w->d_resid.as<float>(), Wf + ly.ln1_w,
+                           Wf + ly.ln1_b, Mt, d, w->d_ln.as<bf16>());
+        launch_gemm<EPI_QKV>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)Mt, 3 * d, d, Wf + ly.qkv_b, w->d_qk.as<bf16>(), 2 * d, 0, 1,
+                             reinterpret_cast<const float *>(w->d_vt.as<bf16>()), T_pad, 2 * d, SPD);
+        attn(w->d_qk.as<bf16>(), 2 * d, w->d_qk.as<bf16>() + d, 2 * d, w->d_vt.as<bf16>(), (int64_t)d * SPD, SPD, T0, TL, 1);
+        launch_gemm<EPI_RESID_F32>(c, w->d_attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)Mt, d, d, Wf + ly.out_b, w->d_resid.as<float>(), d, 0, 1);
+        // cross attention over the audio features
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(Mt, 4)), dim3(256), 0, c->stream, w->d_resid.as<float>(), Wf + ly.lnx_w,
+                           Wf + ly.lnx_b, Mt, d, w->d_ln.as<bf16>());
+        launch_gemm<EPI_BF16>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.xq_w, (int)Mt, d, d, Wf + ly.xq_b, w->d_q.as<bf16>(), d, 0, 1);
+        launch_gemm<EPI_QKV>(c, w->d_enc_bf16.as<bf16>(), d, 0, Wb + ly.xkv_w, (int)Ma, 2 * d, d, Wf + ly.xkv_b, xk, d, 0, 1,
+                             reinterpret_cast<const float *>(xvt), W_CTX, d, AT_SP);
+        attn(w->d_q.as<bf16>(), d, xk, d, xvt, (int64_t)d * AT_SP, AT_SP, A0, AL, 0);
+        const int ns_l = layer_first[(size_t)l + 1] - layer_first[(size_t)l];
+        if (ns_l > 0) {
+            AlignArgs g{};
+            g.q = w->d_q.as<bf16>(); g.q_ld = d; g.k = xk; g.k_ld = d; g.t_len = TL; g.f_len = FL;
+            g.heads = w->d_heads.as<int>() + layer_first[(size_t)l];
+            g.w = w->d_aw.as<float>(); g.sel0 = layer_first[(size_t)l]; g.n_sel_total = n_sel; g.T_pad = T_pad; g.F_pad = F_pad;
+            g.scale = 0.125f * qk_scale;
+            hipLaunchKernelGGL(k_align_scores, dim3((unsigned)div_up(T_pad, 16), (unsigned)ns_l, (unsigned)n), dim3(256), 0, c->stream, g);
+        }
+        launch_gemm<EPI_RESID_F32>(c, w->d_attn.as<bf16>(), d, 0, Wb + ly.xout_w, (int)Mt, d, d, Wf + ly.xout_b, w->d_resid.as<float>(), d, 0, 1);
+        // MLP
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(Mt, 4)), dim3(256), 0, c->stream, w->d_resid.as<float>(), Wf + ly.ln2_w,
+                           Wf + ly.ln2_b, Mt, d, w->d_ln.as<bf16>());
+        launch_gemm<EPI_GELU_BF16>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.m1_w, (int)Mt, 4 * d, d, Wf + ly.m1_b, w->d_hidden.as<bf16>(), 4 * d, 0, 1);
+        launch_gemm<EPI_RESID_F32>(c, w->d_hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, (int)Mt, d, 4 * d, Wf + ly.m2_b, w->d_resid.as<float>(), d, 0, 1);
+    }
+    // alignment matrix: normalise over tokens, median filter over time, mean over heads, DTW
+    hipLaunchKernelGGL(k_align_colnorm, dim3((unsigned)div_up(F_pad, 256), (unsigned)n_sel, (unsigned)n), dim3(256), 0, c->stream,
+                       w->d_aw.as<float>(), TL, FL, n_sel, T_pad, F_pad);
+    hipLaunchKernelGGL(k_align_cost, dim3((unsigned)div_up(F_pad, 256), (unsigned)N_max, (unsigned)n), dim3(256), 0, c->stream,
+                       w->d_aw.as<float>(), TL, FL, n_sel, T_pad, F_pad, (int)sot_len, (int)medfilt_width, N_max, w->d_cost.as<double>());
+    int rc = pce_dtw_launch(c, w->d_cost.as<double>(), (int64_t)N_max * F_pad, F_pad, NR, FL, N_max, F_max, n, w->d_trace.as<unsigned char>(),
+                            w->d_pi.as<int>(), w->d_pj.as<int>(), w->d_pl.as<int>());
+    if (rc) return rc;
+    PCE_HIP(c, hipGetLastError());
+    w->al_n = n; w->al_Nmax = N_max; w->al_Fpad = F_pad; w->al_Mmax = F_max;
+    return PCE_OK;
+}
+
+int pce_whisper_align_fetch(pce_ctx *c, int32_t clip, int32_t *text_idx, int32_t *time_idx, int32_t *path_len, double *cost)
+{
+    if (!c || !path_len) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (w->al_n < 0) return pce_fail(c, PCE_E_STATE, "pce_whisper_align_fetch before pce_whisper_align_run");
+    if (clip < 0 || clip >= w->al_n) return pce_fail(c, PCE_E_INVALID, "clip out of range");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const size_t stride = (size_t)(w->al_Nmax + w->al_Mmax);
+    int n = 0;
+    PCE_HIP(c, hipMemcpyAsync(&n, w->d_pl.as<int>() + clip, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    *path_len = n;
+    if (text_idx) PCE_HIP(c, hipMemcpyAsync(text_idx, w->d_pi.as<int>() + stride * (size_t)clip, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (time_idx) PCE_HIP(c, hipMemcpyAsync(time_idx, w->d_pj.as<int>() + stride * (size_t)clip, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (cost) {
+        const int N = w->al_rows[(size_t)clip], F = w->al_cols[(size_t)clip];
+        PCE_HIP(c, hipMemcpy2DAsync(cost, sizeof(double) * (size_t)F, w->d_cost.as<double>() + (size_t)clip * w->al_Nmax * (size_t)w->al_Fpad,
+                                    sizeof(double) * (size_t)w->al_Fpad, sizeof(double) * (size_t)F, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    }
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    return PCE_OK;
+}
+
+int pce_whisper_align_shape(pce_ctx *c, int32_t clip, int32_t *n_rows, int32_t *n_cols)
+{
+    if (!c) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (w->al_n < 0) return pce_fail(c, PCE_E_STATE, "pce_whisper_align_shape before pce_whisper_align_run");
+    if (clip < 0 || clip >= w->al_n) return pce_fail(c, PCE_E_INVALID, "clip out of range");
+    if (n_rows) *n_rows = w->al_rows[(size_t)clip];
+    if (n_cols) *n_cols = w->al_cols[(size_t)clip];
     return PCE_OK;
 }
 

@@ -66,6 +66,10 @@ class WhisperDims(C.Structure):
     _fields_ = [("n_mels", C.c_int32), ("n_ctx", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32)]
 
 
+class WhisperTextDims(C.Structure):
+    _fields_ = [("n_vocab", C.c_int32), ("n_text_ctx", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32)]
+
+
 SLICE_DTYPE = np.dtype([("clip", "<i4"), ("flags", "<i4"), ("begin", "<i8"), ("end", "<i8"), ("x1", "<f8")])
 ENERGY_DTYPE = np.dtype([("n", "<i8"), ("sum_sq", "<i8"), ("sum_sq_wrap16", "<i8"), ("n_loud", "<i8"),
                          ("peak_abs", "<i4"), ("reserved", "<i4")])
@@ -77,7 +81,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -86,7 +90,8 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
+           "pce_dtw", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch",
+           "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
 
@@ -119,6 +124,10 @@ def load_library() -> C.CDLL:
     lib.pce_resample_run.argtypes = [vp, i32, i32, vp, i32, i64]
     lib.pce_download_pcm_s16.argtypes = [vp, vp, vp, C.POINTER(i32)]
     lib.pce_dtw.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.pce_whisper_decoder_load.argtypes = [vp, C.POINTER(WhisperTextDims), vp, i64]
+    lib.pce_whisper_align_run.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_float]
+    lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_logmel_run.argtypes = [vp, i32]
     lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
@@ -330,6 +339,35 @@ class ProsodyEngine:
     def whisper_encode_fetch(self, clip: int) -> np.ndarray:
         out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)
         self._check(self._lib.pce_whisper_encode_fetch(self._ctx, int(clip), out.ctypes.data))
+        return out
+
+    def whisper_decoder_load(self, dims: dict, weights: np.ndarray):
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        self._tdims = WhisperTextDims(dims["n_vocab"], dims["n_text_ctx"], dims["n_state"], dims["n_head"], dims["n_layer"])
+        self._check(self._lib.pce_whisper_decoder_load(self._ctx, C.byref(self._tdims), w.ctypes.data, w.size))
+
+    def whisper_align(self, token_lists, num_frames, sot_len: int, head_mask=None, medfilt_width: int = 7, qk_scale: float = 1.0,
+                      want_cost: bool = False):
+        """Forced alignment of the given token sequences (one per clip, specials included) against the encoded audio.
+        Returns per clip a dict(text_indices, time_indices[, cost]) -- openai-whisper ``find_alignment`` up to the DTW."""
+        toks = np.concatenate([np.asarray(t, dtype=np.int32) for t in token_lists]).astype(np.int32)
+        off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
+        nf = np.ascontiguousarray(num_frames, dtype=np.int32)
+        hm = None if head_mask is None else np.ascontiguousarray(head_mask, dtype=np.uint8)
+        self._check(self._lib.pce_whisper_align_run(self._ctx, toks.ctypes.data, off.ctypes.data, nf.ctypes.data, int(sot_len),
+                                                    hm.ctypes.data if hm is not None else None, int(medfilt_width), float(qk_scale)))
+        out = []
+        for i in range(len(token_lists)):
+            nr = C.c_int32(); nc = C.c_int32()
+            self._check(self._lib.pce_whisper_align_shape(self._ctx, i, C.byref(nr), C.byref(nc)))
+            ti = np.zeros(nr.value + nc.value, dtype=np.int32); tj = np.zeros(nr.value + nc.value, dtype=np.int32); pl = C.c_int32()
+            cost = np.zeros((nr.value, nc.value), dtype=np.float64) if want_cost else None
+            self._check(self._lib.pce_whisper_align_fetch(self._ctx, i, ti.ctypes.data, tj.ctypes.data, C.byref(pl),
+                                                          cost.ctypes.data if want_cost else None))
+            r = {"text_indices": ti[:pl.value].copy(), "time_indices": tj[:pl.value].copy()}
+            if want_cost:
+                r["cost"] = cost
+            out.append(r)
         return out
 
     def dtw(self, cost: np.ndarray):

@@ -47,3 +47,52 @@ def synthetic_weights(dims, seed=20240930):
 
 def pack(W, dims) -> np.ndarray:
     return np.concatenate([np.asarray(W[name], dtype=np.float32).reshape(-1) for name, _ in tensor_order(dims)])
+
+
+# ------------------------------------------------------------------ text decoder
+TEXT_DIMS = {
+    "tiny": dict(n_vocab=51865, n_text_ctx=448, n_state=384, n_head=6, n_layer=4),
+    "base": dict(n_vocab=51865, n_text_ctx=448, n_state=512, n_head=8, n_layer=6),
+    "small": dict(n_vocab=51865, n_text_ctx=448, n_state=768, n_head=12, n_layer=12),
+    "medium": dict(n_vocab=51865, n_text_ctx=448, n_state=1024, n_head=16, n_layer=24),
+}
+
+
+def decoder_tensor_order(dims):
+    d = dims["n_state"]
+    order = [("token_embedding.weight", (dims["n_vocab"], d)), ("positional_embedding", (dims["n_text_ctx"], d))]
+    for l in range(dims["n_layer"]):
+        p = f"blocks.{l}."
+        for att in ("attn", "cross_attn"):
+            order += [(p + att + "_ln.weight", (d,)), (p + att + "_ln.bias", (d,)),
+                      (p + att + ".query.weight", (d, d)), (p + att + ".query.bias", (d,)), (p + att + ".key.weight", (d, d)),
+                      (p + att + ".value.weight", (d, d)), (p + att + ".value.bias", (d,)),
+                      (p + att + ".out.weight", (d, d)), (p + att + ".out.bias", (d,))]
+        order += [(p + "mlp_ln.weight", (d,)), (p + "mlp_ln.bias", (d,)), (p + "mlp.0.weight", (4 * d, d)), (p + "mlp.0.bias", (4 * d,)),
+                  (p + "mlp.2.weight", (d, 4 * d)), (p + "mlp.2.bias", (d,))]
+    order += [("ln.weight", (d,)), ("ln.bias", (d,))]
+    return order
+
+
+def synthetic_decoder_weights(dims, seed=448):
+    rng = np.random.default_rng(seed)
+    W = {}
+    for name, shape in decoder_tensor_order(dims):
+        if name.endswith("ln.weight"):
+            W[name] = (1.0 + 0.05 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith("ln.bias"):
+            W[name] = (0.02 * rng.standard_normal(shape)).astype(np.float32)
+        elif name in ("token_embedding.weight", "positional_embedding"):   # (checked before the generic Linear branch)
+            W[name] = (0.5 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            b = 1.0 / np.sqrt(shape[1] if len(shape) > 1 else shape[0])
+            W[name] = rng.uniform(-b, b, size=shape).astype(np.float32)
+    # make cross-attention peaky enough to resemble a trained aligner: larger query/key gains
+    for name in W:
+        if "cross_attn.query.weight" in name or "cross_attn.key.weight" in name:
+            W[name] *= 3.0
+    return W
+
+
+def pack_decoder(W, dims) -> np.ndarray:
+    return np.concatenate([np.asarray(W[name], dtype=np.float32).reshape(-1) for name, _ in decoder_tensor_order(dims)])

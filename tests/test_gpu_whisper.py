@@ -74,3 +74,37 @@ def test_dtw_indices_bit_exact(engine):
         wi, wj = WO.dtw_path(x)
         assert np.array_equal(gi, wi) and np.array_equal(gj, wj)
         assert gi[0] == 0 and gj[0] == 0 and gi[-1] == 89 and gj[-1] == 1499 and np.all(np.diff(gi) >= 0) and np.all(np.diff(gj) >= 0)
+
+
+def test_forced_alignment_matches_torch(engine, clips):
+    """Teacher-forced decoder + cross-attention alignment (openai-whisper find_alignment up to the DTW path).
+    The cost matrix agrees with the torch fp32 restatement within bf16 tolerance; the GPU DTW path is EXACTLY the
+    CPU recurrence's path on the GPU's own cost matrix (alignment indices bit-exact given identical costs)."""
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=4)
+    We, Wd = WW.synthetic_weights(edims), WW.synthetic_decoder_weights(tdims)
+    use = clips[:2]
+    engine.upload(use, 16000)
+    engine.logmel_run(80)
+    engine.whisper_load(edims, WW.pack(We, edims))
+    engine.whisper_encode_run()
+    engine.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+    rng = np.random.default_rng(21)
+    sot_len = 3
+    toks = [rng.integers(0, 300, size=n).tolist() for n in (37, 70)]
+    num_frames = [len(c) // 160 for c in use]                      # mel frames of the real audio
+    res = engine.whisper_align(toks, num_frames, sot_len, want_cost=True)
+    for i in range(2):
+        enc = engine.whisper_encode_fetch(i)                       # same audio features for both sides
+        cost, ti, tj = WO.find_alignment(toks[i], enc, Wd, tdims, num_frames[i], sot_len)
+        got = res[i]
+        assert got["cost"].shape == cost.shape == (len(toks[i]) - sot_len - 1, num_frames[i] // 2)
+        assert np.max(np.abs(got["cost"] - cost)) <= 0.08                                    # observed 0.035 at std 0.4
+        assert np.linalg.norm(got["cost"] - cost) / np.linalg.norm(cost) <= 3e-2            # observed 9e-3 (bf16 operands)
+        wi, wj = WO.dtw_path(got["cost"])
+        assert np.array_equal(got["text_indices"], wi) and np.array_equal(got["time_indices"], wj)
+        # and the path agrees with the torch path almost everywhere (costs differ by bf16 rounding)
+        n = min(len(ti), len(got["text_indices"]))
+        jumps_g = got["time_indices"][np.r_[True, np.diff(got["text_indices"]) > 0]]
+        jumps_w = tj[np.r_[True, np.diff(ti) > 0]]
+        assert len(jumps_g) == len(jumps_w) and np.mean(np.abs(jumps_g - jumps_w) <= 1) >= 0.95          # observed: identical
