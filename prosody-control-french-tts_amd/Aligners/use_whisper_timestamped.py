@@ -1,9 +1,10 @@
 """Noise / silence gate of the aligner (``Code/Aligners/use_whisper_timestamped.py:197-229`` and its
 inline copy :581-599) on the GPU, plus the JSON -> TextGrid conversion of :330-395.
 
-The transcription itself (Whisper decoder, cross-attention DTW, word timestamps) is not part of
-this build yet: the encoder half runs on the engine (``ProsodyEngine.whisper_encode_*``),
-``main()`` raises ``NotImplementedError`` until the decoder row of SURVEY.md section 8f lands."""
+What runs on the engine: the gate, the 16 kHz resampler, log-mel, the audio encoder and the forced
+alignment of *given* token ids (teacher-forced text decoder, alignment-head cross-attention, DTW:
+``ProsodyEngine.whisper_align``).  Free-running transcription needs the trained checkpoint and the
+tokenizer vocabulary, neither of which is available offline, so ``main()`` raises ``NotImplementedError``."""
 import os
 
 from .. import hostrules as H
@@ -56,5 +57,5 @@ def json_to_textgrid(json_file, logger=None):
 
 
 def main(audio_path, out_path, whisper_model="medium", device=None, logger=None):
-    raise NotImplementedError("Whisper decoding + word-timestamp DTW are not built yet (SURVEY.md section 8f, row 2); "
-                              "the gate (check_audio_content_batch), the log-mel front end and the audio encoder are.")
+    raise NotImplementedError("free-running Whisper transcription (checkpoint + tokenizer) is not available in this build; the gate, "
+                              "resampler, log-mel, encoder and token-level forced alignment (ProsodyEngine.whisper_align) are")
