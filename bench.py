@@ -96,7 +96,7 @@ def main():
     eng = pkg.ProsodyEngine(local_rank)
     eng.upload(clips, rate)                      # inputs resident in HBM before the timed region
     sl = eng.whole_clip_slices()
-    params = pkg.PitchParams.praat(150.0, 600.0)
+    params = pkg.PitchParams.praat(float(os.environ.get("PCE_BENCH_FLOOR", "150")), 600.0)   # reference: floor 150 (Code/audioPipeline.py:329)
     off, _ = eng.pitch_plan(sl, params)
     n_pitch_frames = int(off[1] - off[0])
     n_stft_frames = 1 + n_samples // 256

@@ -82,7 +82,7 @@ constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte line
 
 struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
-    int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, tab_lds, pad2;
+    int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, mode, fpb;
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -214,7 +214,119 @@ __device__ double2 *fft_wave(double2 *src, double2 *dst, int M, const double2 *_
     return src;
 }
 
-__global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
+
+// ---------------------------------------------------------------------------
+// M = 512 (16 kHz at Praat's 75 Hz floor: N = 1024) keeps the whole transform in registers:
+// 512 = 8 x 8 x 8, eight complex points per lane, three radix-8 butterflies per lane and two
+// transposes through ONE 9 KB LDS exchange buffer per wavefront.  LDS stores are the scarce
+// resource here (ds_write_b128: ~79 B/clk/CU against 256 B/clk for reads), and this form
+// stores 40 KB per frame where the ping-pong Stockham passes store ~115 KB; the single buffer
+// also doubles the wavefronts a CU can hold.
+//   stage 1: lane l holds x[64 a + l]        -> DFT over a, twiddle W512^(l k0)
+//   stage 2: lane (c + 8 k0) holds y1[k0][8 b + c] -> DFT over b, twiddle W64^(c k1)
+//   stage 3: lane (k0 + 8 k1) holds y2[k0][k1][c]  -> DFT over c: X[k0 + 8 k1 + 64 k2]
+// so the result comes back in the layout stage 1 started from (index = lane + 64 r).
+// Exchange images: [k0][72] and [c][65] complex: ds_write_b128 (8 contiguous lanes per group,
+// 128-byte bank rows) and ds_read_b128 (16-lane groups, 256-byte rows) are both conflict-free.
+// ---------------------------------------------------------------------------
+constexpr int R_WAVE_F64 = 2 * 8 * 72;              // doubles of LDS per wavefront on the register paths
+__device__ __forceinline__ void dft8_f64(double2 (&a)[8])
+{
+    const double r = 0.70710678118654752440;
+    const double2 b0 = make_double2(a[0].x + a[4].x, a[0].y + a[4].y), b4 = make_double2(a[0].x - a[4].x, a[0].y - a[4].y);
+    const double2 b1 = make_double2(a[1].x + a[5].x, a[1].y + a[5].y), t5 = make_double2(a[1].x - a[5].x, a[1].y - a[5].y);
+    const double2 b2 = make_double2(a[2].x + a[6].x, a[2].y + a[6].y), t6 = make_double2(a[2].x - a[6].x, a[2].y - a[6].y);
+    const double2 b3 = make_double2(a[3].x + a[7].x, a[3].y + a[7].y), t7 = make_double2(a[3].x - a[7].x, a[3].y - a[7].y);
+    const double2 b5 = make_double2(r * (t5.x + t5.y), r * (t5.y - t5.x));        // * exp(-i pi/4)
+    const double2 b6 = make_double2(t6.y, -t6.x);                                 // * (-i)
+    const double2 b7 = make_double2(r * (t7.y - t7.x), -(r * (t7.x + t7.y)));     // * exp(-3 i pi/4)
+    const double2 c0 = make_double2(b0.x + b2.x, b0.y + b2.y), c2 = make_double2(b0.x - b2.x, b0.y - b2.y);
+    const double2 c1 = make_double2(b1.x + b3.x, b1.y + b3.y), c3 = make_double2(b1.y - b3.y, -(b1.x - b3.x));
+    const double2 d0 = make_double2(b4.x + b6.x, b4.y + b6.y), d2 = make_double2(b4.x - b6.x, b4.y - b6.y);
+    const double2 d1 = make_double2(b5.x + b7.x, b5.y + b7.y), d3 = make_double2(b5.y - b7.y, -(b5.x - b7.x));
+    a[0] = make_double2(c0.x + c1.x, c0.y + c1.y); a[4] = make_double2(c0.x - c1.x, c0.y - c1.y);
+    a[2] = make_double2(c2.x + c3.x, c2.y + c3.y); a[6] = make_double2(c2.x - c3.x, c2.y - c3.y);
+    a[1] = make_double2(d0.x + d1.x, d0.y + d1.y); a[5] = make_double2(d0.x - d1.x, d0.y - d1.y);
+    a[3] = make_double2(d2.x + d3.x, d2.y + d3.y); a[7] = make_double2(d2.x - d3.x, d2.y - d3.y);
+}
+// forward DFT of 512 points held as z[r] = x[lane + 64 r]; returns X[lane + 64 r] in z[r]
+__device__ __forceinline__ void fft512_reg(double2 (&z)[8], double2 *ex, const double2 *__restrict__ twM, int lane)
+{
+    dft8_f64(z);
+#pragma unroll
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[lane * k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ex[72 * k + lane] = z[k];
+    wave_sync();
+    const int c = lane & 7, k0 = lane >> 3;
+#pragma unroll
+    for (int b = 0; b < 8; b++) z[b] = ex[72 * k0 + 8 * b + c];
+    wave_sync();
+    dft8_f64(z);
+#pragma unroll
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[8 * c * k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ex[65 * c + k0 + 8 * k] = z[k];
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 8; q++) z[q] = ex[65 * q + lane];
+    wave_sync();
+    dft8_f64(z);
+}
+
+// forward DFT of 256 points by a HALF wavefront (two frames per wavefront): 256 = 8 x 8 x 4,
+// z[r] = x[hl + 32 r] in, X[hl + 32 r] out, hl = lane within the half.  Exchange images
+// [k0][36] and [c][66] complex in this frame's 288-complex region (conflict-free as above).
+__device__ __forceinline__ void fft256_half(double2 (&z)[8], double2 *ex, const double2 *__restrict__ twM, int hl)
+{
+    dft8_f64(z);
+#pragma unroll
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[hl * k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ex[36 * k + hl] = z[k];
+    wave_sync();
+    const int c = hl & 3, k0 = hl >> 2;
+#pragma unroll
+    for (int b = 0; b < 8; b++) z[b] = ex[36 * k0 + 4 * b + c];
+    wave_sync();
+    dft8_f64(z);
+#pragma unroll
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[8 * c * k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ex[66 * c + k0 + 8 * k] = z[k];
+    wave_sync();
+    double2 v[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[g][q] = ex[66 * q + 32 * g + hl];
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const double2 t0 = make_double2(v[g][0].x + v[g][2].x, v[g][0].y + v[g][2].y), t1 = make_double2(v[g][0].x - v[g][2].x, v[g][0].y - v[g][2].y);
+        const double2 t2 = make_double2(v[g][1].x + v[g][3].x, v[g][1].y + v[g][3].y), t3 = make_double2(v[g][1].y - v[g][3].y, -(v[g][1].x - v[g][3].x));
+        z[g] = make_double2(t0.x + t2.x, t0.y + t2.y);     z[2 + g] = make_double2(t1.x + t3.x, t1.y + t3.y);
+        z[4 + g] = make_double2(t0.x - t2.x, t0.y - t2.y); z[6 + g] = make_double2(t1.x - t3.x, t1.y - t3.y);
+    }
+}
+
+template <int W> __device__ __forceinline__ int group_sum_i32(int v)
+{
+    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int W> __device__ __forceinline__ double group_max_f64(double v)
+{
+    for (int off = W / 2; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// MODE 0: any N, one frame per wavefront, Stockham passes between two LDS buffers.
+// MODE 1: N = 1024, one frame per wavefront, register-resident transform.
+// MODE 2: N = 512 (16 kHz at the reference's 150 Hz floor, Code/audioPipeline.py:329), TWO frames per
+//         wavefront (one per 32-lane half), register-resident transform.
+template <int WPB, int MODE>
+__global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const int16_t *__restrict__ pcm, const PiSlice *__restrict__ slices, const PiWork *__restrict__ work, int n_work,
     PiParams P, const double *__restrict__ window, const double *__restrict__ windowR,
     const double2 *__restrict__ twM /* exp(-2 pi i m / M), m < M */, const double2 *__restrict__ twN /* exp(-2 pi i k / N), k <= M */,
@@ -223,23 +335,30 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
     double *__restrict__ rr_out /* [frames][rr_len] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
     unsigned int list_cap, int dbg)
 {
+    constexpr int LW = MODE == 2 ? 32 : 64;              // lanes per frame
+    constexpr int FPW = 64 / LW;                         // frames per wavefront
+    constexpr int FPB = MODE == 2 ? 2 * PI_FPB : PI_FPB; // frames per work item (host: P.fpb)
+    constexpr int MR = 8 * LW;                           // M on the register paths
+    constexpr int REG_C = R_WAVE_F64 / 2 / FPW;          // complex slots per frame on the register paths
     extern __shared__ double lds[];
     // XCD-aware remap: consecutive work items (overlapping windows of one slice) go to one XCD's L2
     const int nb = (int)gridDim.x;
     int bid = (int)blockIdx.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int hl = lane & (LW - 1), half = lane / LW;    // lane within the frame's group; the group
     const int M = P.nfft >> 1;
     if (bid >= n_work) return;
     const PiWork wk = work[bid];
     const PiSlice s = slices[wk.slice];
-    double2 *bufA = reinterpret_cast<double2 *>(lds) + (size_t)wv * (size_t)(2 * P.zlen);
-    double2 *bufB = bufA + P.zlen;
-    double *xr = reinterpret_cast<double *>(bufA);      // real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
-    // each wavefront walks PI_FPB / PI_WPB frames of the work item (the table copy above is paid once per item)
-    for (int fi = wv; fi < PI_FPB; fi += (int)(blockDim.x >> 6)) {
-    const int iframe = wk.frame0 + fi;                  // 0-based
-    if (iframe >= s.n_frames) break;
+    double2 *wave_base = reinterpret_cast<double2 *>(lds) + (MODE == 0 ? (size_t)wv * (size_t)(2 * P.zlen) : (size_t)wv * (R_WAVE_F64 / 2));
+    double2 *bufA = MODE == 0 ? wave_base : wave_base + half * REG_C;
+    double2 *bufB = bufA + P.zlen;                      // (MODE 0 only)
+    double *xr = reinterpret_cast<double *>(bufA);      // MODE 0: real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
+    for (int fi = wv * FPW; fi < FPB; fi += WPB * FPW) {
+    const int iframe = wk.frame0 + fi + half;           // 0-based
+    const bool live = iframe < s.n_frames;
+    if (__ballot(live) == 0) break;
     const int64_t fidx = s.frame_off + iframe;
     wave_sync();                                        // the previous frame's LDS reads are done
 
@@ -263,6 +382,42 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
     const int64_t ws = L0 + 1 - P.hw;                             // first sample of the window (slice-relative)
     const int64_t m0 = L0 + 1 - P.nsp, m1 = L0 + P.nsp;           // local-mean range, inclusive
 
+    double2 z[8];                                        // register paths: z[r] = x[2n] + i x[2n+1], n = hl + LW r
+    double lpk = 0.0;
+    const int pk0 = max(P.hw + 1 - P.hsp, 1), pk1 = min(P.hw + P.hsp, P.nw);   // 1-based inclusive
+    if constexpr (MODE != 0) {
+        int isum = 0, v[16];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = 2 * (hl + LW * r) + h;
+                int x = 0;
+                if (live && j < P.nw) {
+                    const int64_t rel = ws + j, cc = s.begin + rel;
+                    if (rel >= 0 && rel < s.nx && cc >= 0 && cc < s.clip_len) x = (int)pcm[s.clip_off + cc];
+                    if (rel >= m0 && rel <= m1) isum += x;
+                }
+                v[2 * r + h] = x;
+            }
+        }
+        isum = group_sum_i32<LW>(isum);
+        const double localMean = ((double)isum / 32768.0) / (double)(2 * P.nsp);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            double f[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = 2 * (hl + LW * r) + h;
+                f[h] = 0.0;
+                if (live && j < P.nw) {
+                    f[h] = ((double)v[2 * r + h] / 32768.0 - localMean) * window[j];
+                    if (j + 1 >= pk0 && j + 1 <= pk1) lpk = fmax(lpk, fabs(f[h]));
+                }
+            }
+            z[r] = make_double2(f[0], f[1]);
+        }
+    } else {
     // stage raw samples (exact in fp64) and the integer local sum
     int isum = 0;
     for (int j = lane; j < P.nfft; j += 64) {
@@ -276,22 +431,60 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
     }
     isum = wave_sum_i32(isum);
     const double localMean = ((double)isum / 32768.0) / (double)(2 * P.nsp);
-    double lpk = 0.0;
-    const int pk0 = max(P.hw + 1 - P.hsp, 1), pk1 = min(P.hw + P.hsp, P.nw);   // 1-based inclusive
     for (int j = lane; j < P.nw; j += 64) {
         const int a = 2 * ZP(j >> 1) + (j & 1);
         const double f = (xr[a] - localMean) * window[j];
         xr[a] = f;
         if (j + 1 >= pk0 && j + 1 <= pk1) lpk = fmax(lpk, fabs(f));
     }
-    const double localPeak = wave_max_f64(lpk);
+    }
+    const double localPeak = group_max_f64<LW>(lpk);
     const double inten = localPeak > globalPeak ? 1.0 : localPeak / globalPeak;
+    const bool active = live && localPeak != 0.0;
 
     double *rr = nullptr;                                // rr[bix + k] = r[k], k in [-bix, bix]
-    // candidate registers: lane q holds candidate q (0 = the voiceless candidate)
+    // candidate registers: group lane q holds candidate q (0 = the voiceless candidate)
     double c_f = 0.0, c_s = 0.0; int c_i = 0; int n = 1;
 
-    if (localPeak != 0.0) {
+    if (__ballot(active) != 0) {
+        if constexpr (MODE != 0) {
+            wave_sync();
+            if constexpr (MODE == 1) fft512_reg(z, bufA, twM, lane); else fft256_half(z, bufA, twM, hl);
+            // power spectrum of the real frame, re-tangled for the second transform.  Lane-local form of
+            // the pairwise loop of MODE 0: for every own k, with zm = Z[M - k],
+            // X[k] = ez + t, X[M - k]* = ez - t, and W[k] = (e - d sin, -d cos) holds for all k in [0, M).
+#pragma unroll
+            for (int r = 0; r < 8; r++) bufA[hl + LW * r] = z[r];
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = hl + LW * r;
+                const double2 zk = z[r], zm = bufA[(MR - k) & (MR - 1)];
+                const double2 w = twN[k];                                     // (cos, -sin)
+                const double2 ez = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+                const double2 oz = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+                const double2 t = cmul_f64(oz, w);
+                const double xr1 = ez.x + t.x, xi1 = ez.y + t.y, xr2 = ez.x - t.x, xi2 = ez.y - t.y;
+                const double pk = fma(xr1, xr1, xi1 * xi1), pm = fma(xr2, xr2, xi2 * xi2);
+                const double e = 0.5 * (pk + pm), d = 0.5 * (pk - pm);
+                z[r] = make_double2(e - d * (-w.y), -(d * w.x));
+            }
+            wave_sync();
+            if constexpr (MODE == 1) fft512_reg(z, bufA, twM, lane); else fft256_half(z, bufA, twM, hl);
+            // ac[2n] = Re Y[n], ac[2n+1] = -Im Y[n]; r[k] = ac[k] / (ac[0] windowR[k]) into the same region
+            rr = reinterpret_cast<double *>(bufA);
+            const double ac0 = __shfl(z[0].x, lane & ~(LW - 1), 64);
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int k = 2 * (hl + LW * r);
+                    if (k >= 1 && k <= P.bix) { const double v = z[r].x / (ac0 * windowR[k]); rr[P.bix + k] = v; rr[P.bix - k] = v; }
+                    if (k + 1 <= P.bix) { const double v = -z[r].y / (ac0 * windowR[k + 1]); rr[P.bix + k + 1] = v; rr[P.bix - k - 1] = v; }
+                }
+                if (hl == 0) rr[P.bix] = 1.0;
+            }
+            wave_sync();
+        } else {
         wave_sync();
         // forward transform of the packed frame
         double2 *Z = (dbg & 1) ? bufA : fft_wave(bufA, bufB, M, twM, lane);
@@ -322,6 +515,7 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
         }
         if (lane == 0) rr[P.bix] = 1.0;
         wave_sync();
+        }
 
         const int ynx = 2 * P.bix + 1;
         const int lim = min(P.maxlag, P.bix);
@@ -329,36 +523,43 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
         // count the local maxima first: with at most maxc-1 of them (the common case) every
         // maximum becomes a candidate and the first-pass strength is never consulted.
         int total = 0;
-        for (int base = 2; base < lim; base += 64) {
-            const int i = base + lane;
+        for (int base = 2; base < lim; base += LW) {
+            const int i = base + hl;
             bool pred = false;
-            if (i < lim) {
+            if (active && i < lim) {
                 const double r0 = rr[P.bix + i], rm = rr[P.bix + i - 1], rp = rr[P.bix + i + 1];
                 pred = r0 > half_vt && r0 > rm && r0 >= rp;
             }
-            const unsigned long long mask = __ballot(pred);
+            unsigned long long mask = __ballot(pred);
+            if (LW == 32) mask = (mask >> (32 * half)) & 0xffffffffull;
             const int here = __popcll(mask);
             if (total + here <= P.maxc - 1) {
                 // the lane that owns slot (1 + total + q) takes the lag of the q-th maximum of this round
-                const int need = lane - 1 - total;
+                const int need = hl - 1 - total;
                 if (need >= 0 && need < here) {
                     unsigned long long m = mask;
                     for (int q = 0; q < need; q++) m &= m - 1;
                     c_i = base + __ffsll((long long)m) - 1;
                 }
             }
-            total += __popcll(mask);
+            total += here;
         }
-        if (total <= P.maxc - 1) {
-            n = 1 + total;
-        } else {
-            // rare: more maxima than candidate slots -> Praat's replacement rule needs first-pass strengths
-            c_i = 0;
+        const bool rare = total > P.maxc - 1;
+        if (!rare) n = 1 + total;
+        // rare: more maxima than candidate slots -> Praat's replacement rule needs first-pass strengths.
+        // The whole wavefront works on one frame at a time here (sinc_wave spreads its terms over 64 lanes).
+        const unsigned long long rare_mask = __ballot(rare);
+        for (int g = 0; g < FPW; g++) {
+            if (!((rare_mask >> (g * LW)) & 1ull)) continue;
+            const double *rg = FPW == 1 ? rr : reinterpret_cast<const double *>(wave_base + g * REG_C);
+            const bool mine = half == g;
+            int ng = 1;
+            if (mine) c_i = 0;
             for (int base = 2; base < lim; base += 64) {
                 const int i = base + lane;
                 bool pred = false;
                 if (i < lim) {
-                    const double r0 = rr[P.bix + i], rm = rr[P.bix + i - 1], rp = rr[P.bix + i + 1];
+                    const double r0 = rg[P.bix + i], rm = rg[P.bix + i - 1], rp = rg[P.bix + i + 1];
                     pred = r0 > half_vt && r0 > rm && r0 >= rp;
                 }
                 unsigned long long mask = __ballot(pred);
@@ -366,19 +567,19 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
                     const int bpos = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const int im = base + bpos;
-                    const double r0 = rr[P.bix + im], rm = rr[P.bix + im - 1], rp = rr[P.bix + im + 1];
+                    const double r0 = rg[P.bix + im], rm = rg[P.bix + im - 1], rp = rg[P.bix + im + 1];
                     const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
                     const double fmx = 1.0 / P.dx / ((double)im + dr / d2r);
-                    double smx = sinc_wave(rr, ynx, 1.0 / P.dx / fmx + (double)(P.bix + 1), 30, lane);
+                    double smx = sinc_wave(rg, ynx, 1.0 / P.dx / fmx + (double)(P.bix + 1), 30, lane);
                     if (smx > 1.0) smx = 1.0 / smx;
                     int place = -1;
-                    if (n < P.maxc) {
-                        place = n++;
+                    if (ng < P.maxc) {
+                        place = ng++;
                     } else {
                         // weakest candidate so far among 1..maxc-1 (first minimum wins)
                         double ls = c_s - P.octave_cost * (log(P.min_pitch / c_f) * LOG2E_D);
-                        int li = lane;
-                        if (lane < 1 || lane >= P.maxc) { ls = 1e300; li = 1 << 20; }
+                        int li = hl;
+                        if (!mine || hl < 1 || hl >= P.maxc) { ls = 1e300; li = 1 << 20; }
                         for (int off = 32; off > 0; off >>= 1) {
                             const double os = __shfl_xor(ls, off, 64);
                             const int oi = __shfl_xor(li, off, 64);
@@ -388,27 +589,28 @@ __global__ __launch_bounds__(64 * PI_WPB, 4) void k_pitch_frames(
                         if (ls < weakest) { weakest = ls; place = li; }
                         if (smx - P.octave_cost * (log(P.min_pitch / fmx) * LOG2E_D) <= weakest) place = -1;
                     }
-                    if (place >= 0 && lane == place) { c_f = fmx; c_s = smx; c_i = im; }
+                    if (place >= 0 && mine && hl == place) { c_f = fmx; c_s = smx; c_i = im; }
                 }
             }
+            if (mine) n = ng;
         }
         if (n > 1 && !(dbg & 2)) {
             // hand r[-bix..bix] and the candidate lags to k_pitch_refine
             double *ro = rr_out + fidx * (int64_t)P.rr_len;
-            for (int k = lane; k < ynx; k += 64) ro[k] = rr[k];
+            for (int k = hl; k < ynx; k += LW) ro[k] = rr[k];
             // append to one of RF_LISTS lists: a single counter would serialise ~10^5 returning atomics in L2
             const unsigned int list = (unsigned int)bid & (RF_LISTS - 1);
             unsigned int pos = 0;
-            if (lane == 0) pos = atomicAdd(item_count + list * RF_CSTRIDE, (unsigned int)(n - 1));
-            pos = __shfl(pos, 0, 64);
-            if (lane >= 1 && lane < n) items[(size_t)list * list_cap + pos + lane - 1] = RefineItem{(long long)fidx, lane, c_i};
+            if (hl == 0) pos = atomicAdd(item_count + list * RF_CSTRIDE, (unsigned int)(n - 1));
+            pos = __shfl(pos, lane & ~(LW - 1), 64);
+            if (hl >= 1 && hl < n) items[(size_t)list * list_cap + pos + hl - 1] = RefineItem{(long long)fidx, hl, c_i};
         }
     }
-    if (lane < PI_MAXC) {
-        cand[fidx * 32 + lane] = 0.0;
-        cand[fidx * 32 + 16 + lane] = 0.0;
+    if (live && hl < PI_MAXC) {
+        cand[fidx * 32 + hl] = 0.0;
+        cand[fidx * 32 + 16 + hl] = 0.0;
     }
-    if (lane == 0) { ncand[fidx] = n; intensity[fidx] = inten; }
+    if (live && hl == 0) { ncand[fidx] = n; intensity[fidx] = inten; }
     }   // frames of this wavefront
 }
 
@@ -964,7 +1166,12 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             P.rr_len = 2 * P.bix + 2;
             const size_t lds_wave = sizeof(double) * 4 * (size_t)P.zlen;            // two complex buffers per wavefront
             if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
-            P.tab_lds = 0;   // copying the tables into LDS per workgroup measured slower (1.77 vs 1.45 ms) than L1-cached global reads
+            // register-resident transforms where N allows it and r[-bix..bix] fits the exchange region
+            // (tables stay in global memory: staging them in LDS per workgroup measured slower than L1 hits)
+            P.mode = getenv("PCE_PITCH_LDS_FFT") ? 0
+                     : (nfft == 1024 && P.rr_len <= R_WAVE_F64) ? 1
+                     : (nfft == 512 && P.rr_len <= R_WAVE_F64 / 2) ? 2 : 0;
+            P.fpb = P.mode == 2 ? 2 * PI_FPB : PI_FPB;
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
             for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
@@ -993,7 +1200,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             if (nf > INT32_MAX) return pce_fail(c, PCE_E_LIMIT, "slice %d has too many frames", i);
             h.n_frames = (int32_t)nf; h.status = c->pi_status[(size_t)i];
             if (nf > max_frames) max_frames = nf;
-            for (int64_t f = 0; f < nf; f += PI_FPB) work.push_back({i, (int32_t)f});
+            for (int64_t f = 0; f < nf; f += P.fpb) work.push_back({i, (int32_t)f});
         }
         int np2 = 1; while (np2 < max_frames) np2 <<= 1;
         if ((size_t)np2 * sizeof(double) > 128 * 1024) return pce_fail(c, PCE_E_LIMIT, "slice with %lld frames exceeds the %d-frame median limit", (long long)max_frames, 16384);
@@ -1011,7 +1218,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         PCE_HIP(c, c->pi_fslice.reserve(sizeof(int) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_dl.reserve(sizeof(double) * 2 * PI_MAXC * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_rr.reserve(sizeof(double) * (size_t)P.rr_len * (size_t)(total + 1)));
-        PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)PI_FPB * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
+        PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)(2 * PI_FPB) * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
                                        + sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE));
         PCE_HIP(c, hipMemcpyAsync(c->pi_meta.p, hs.data(), sizeof(PiSlice) * hs.size(), hipMemcpyHostToDevice, c->stream));
         if (!work.empty())
@@ -1041,22 +1248,35 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             // long windows (44.1 kHz at a 75 Hz floor: 72 KB per wavefront) run fewer wavefronts per workgroup
             int wpb = PI_WPB;
             while (wpb > 1 && sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb > 160 * 1024) wpb >>= 1;
-            const size_t lds = sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb;
+            if (P.mode != 0) wpb = PI_WPB;
+            const size_t lds = P.mode != 0 ? sizeof(double) * (size_t)R_WAVE_F64 * PI_WPB : sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb;
+            const void *kfn = P.mode == 1 ? reinterpret_cast<const void *>(k_pitch_frames<4, 1>)
+                              : P.mode == 2 ? reinterpret_cast<const void *>(k_pitch_frames<4, 2>)
+                              : wpb == 4 ? reinterpret_cast<const void *>(k_pitch_frames<4, 0>)
+                              : wpb == 2 ? reinterpret_cast<const void *>(k_pitch_frames<2, 0>)
+                                         : reinterpret_cast<const void *>(k_pitch_frames<1, 0>);
             if (lds > 64 * 1024)
-                PCE_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pitch_frames), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                PCE_HIP(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const size_t cnt_bytes = sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE;
             RefineItem *items = reinterpret_cast<RefineItem *>(c->pi_items.as<char>() + cnt_bytes);
             unsigned int *item_count = c->pi_items.as<unsigned int>();
-            const unsigned int list_cap = (unsigned int)(div_up(nb, RF_LISTS) * PI_FPB * (PI_MAXC - 1));
+            const unsigned int list_cap = (unsigned int)(div_up(nb, RF_LISTS) * P.fpb * (PI_MAXC - 1));
             PCE_HIP(c, hipMemsetAsync(item_count, 0, cnt_bytes, c->stream));
             {
                 KernelTimer t(c, PCE_K_PITCH_FRAMES);
-                hipLaunchKernelGGL(k_pitch_frames, dim3((unsigned)nb), dim3(64 * wpb), lds, c->stream, c->d_pcm,
-                                   c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,
-                                   c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
-                                   c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
-                                   c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap,
-                                   getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0);
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * wpb), lds, c->stream, c->d_pcm,
+                                       c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,
+                                       c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
+                                       c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
+                                       c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap,
+                                       getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0);
+                };
+                if (P.mode == 1) launch(k_pitch_frames<4, 1>);
+                else if (P.mode == 2) launch(k_pitch_frames<4, 2>);
+                else if (wpb == 4) launch(k_pitch_frames<4, 0>);
+                else if (wpb == 2) launch(k_pitch_frames<2, 0>);
+                else launch(k_pitch_frames<1, 0>);
             }
             {
                 KernelTimer t(c, PCE_K_PITCH_REFINE);

@@ -107,7 +107,7 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
     dft8(a);
 #pragma unroll
     for (int u = 0; u < 8; u++) zb[ZPAD(lane * 8 + u)] = a[u];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // pass 2 (Ns = 8)
     {
@@ -118,12 +118,12 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
         for (int t = 1; t < 8; t++) a[t] = cmul(a[t], C.tw2[t - 1]);
         dft8(a);
         const int base = ((lane - k) << 3) + k;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 8; u++) zb[ZPAD(base + u * 8)] = a[u];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // pass 3 (Ns = 64)
     {
@@ -132,12 +132,12 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
 #pragma unroll
         for (int t = 1; t < 8; t++) a[t] = cmul(a[t], C.tw3[t - 1]);
         dft8(a);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < 8; u++) zb[ZPAD(lane + u * 64)] = a[u];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // untangle the packed real transform: X[k] = E[k] + w^k O[k]
 #pragma unroll
@@ -150,7 +150,7 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
         const float2 x = cadd(e, cmul(C.twu[t], o));
         sink(k, sqrtf(x.x * x.x + x.y * x.y));      // |x| <= 1024: no overflow; np.abs differs by <= 1 ulp
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
             const float v = (i < len) ? (float)pcm[base + i] * (1.0f / 32768.0f) : 0.0f;
             xs[wv][n] = v * T.window[n];
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         // stage A: Y[n2][k1] = sum_{n1<16} x[25 n1 + n2] W16^{n1 k1}, then twiddle W400^{n2 k1}
         for (int o = lane; o < 400; o += 64) {
             const int n2 = o >> 4, k1 = o & 15;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
             const float2 t = s_w400[o];
             ys[wv][o] = make_float2(re * t.x - im * t.y, re * t.y + im * t.x);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         // stage B: X[k1 + 16 k2] = sum_{n2<25} Y[n2][k1] W25^{n2 k2}; only k <= 200 is needed
         for (int k = lane; k < W_BINS; k += 64) {
             const int k1 = k & 15, k2 = k >> 4;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
             }
             pw[wv][k] = re * re + im * im;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         for (int b = lane; b < n_mels; b += 64) {
             const int lo = T.mel_lo[b], cnt = T.mel_n[b];
             const float *w = T.mel_w + T.mel_off[b];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
             logspec[((int64_t)clip * n_mels + b) * W_FRAMES + frame] = lg;
             vmax = fmaxf(vmax, lg);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
     if (lane == 0) atomicMax(clip_max + clip, f32_order_key(vmax));
