@@ -67,7 +67,7 @@ struct pce_ctx {
     std::vector<int32_t> lu_host_status;
 
     // pitch
-    DevBuf pi_meta, pi_window, pi_windowR, pi_work, pi_cand, pi_gpeak, pi_psi, pi_f0, pi_strength, pi_summary, pi_peakwork, pi_acc, pi_rr, pi_items, pi_tw, pi_dl, pi_runs, pi_fslice;
+    DevBuf pi_meta, pi_window, pi_windowR, pi_work, pi_cand, pi_gpeak, pi_psi, pi_f0, pi_strength, pi_summary, pi_peakwork, pi_acc, pi_rr, pi_items, pi_tw, pi_dl, pi_runs, pi_fslice, pi_blob;
     double pi_P[32] = {0};          // PiParams image
     int64_t pi_n_work = 0, pi_n_energy_work = 0;
     int pi_np2 = 1;

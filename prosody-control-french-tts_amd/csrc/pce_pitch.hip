@@ -83,6 +83,7 @@ constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte line
 struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
     int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, mode, fpb;
+    int o_tw2, o_twN, o_win, o_winR, blob_f64, pcm_span, tabs, pad3;   // register paths: table blob layout (offsets in doubles)
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -250,11 +251,11 @@ __device__ __forceinline__ void dft8_f64(double2 (&a)[8])
     a[3] = make_double2(d2.x + d3.x, d2.y + d3.y); a[7] = make_double2(d2.x - d3.x, d2.y - d3.y);
 }
 // forward DFT of 512 points held as z[r] = x[lane + 64 r]; returns X[lane + 64 r] in z[r]
-__device__ __forceinline__ void fft512_reg(double2 (&z)[8], double2 *ex, const double2 *__restrict__ twM, int lane)
+__device__ __forceinline__ void fft512_reg(double2 (&z)[8], double2 *ex, const double2 *tw1 /* [7][64]: W512^(l k) */, const double2 *tw2 /* [7][8]: W64^(c k) */, int lane)
 {
     dft8_f64(z);
 #pragma unroll
-    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[lane * k]);
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], tw1[(k - 1) * 64 + lane]);
 #pragma unroll
     for (int k = 0; k < 8; k++) ex[72 * k + lane] = z[k];
     wave_sync();
@@ -264,7 +265,7 @@ __device__ __forceinline__ void fft512_reg(double2 (&z)[8], double2 *ex, const d
     wave_sync();
     dft8_f64(z);
 #pragma unroll
-    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[8 * c * k]);
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], tw2[(k - 1) * 8 + c]);
 #pragma unroll
     for (int k = 0; k < 8; k++) ex[65 * c + k0 + 8 * k] = z[k];
     wave_sync();
@@ -277,11 +278,11 @@ __device__ __forceinline__ void fft512_reg(double2 (&z)[8], double2 *ex, const d
 // forward DFT of 256 points by a HALF wavefront (two frames per wavefront): 256 = 8 x 8 x 4,
 // z[r] = x[hl + 32 r] in, X[hl + 32 r] out, hl = lane within the half.  Exchange images
 // [k0][36] and [c][66] complex in this frame's 288-complex region (conflict-free as above).
-__device__ __forceinline__ void fft256_half(double2 (&z)[8], double2 *ex, const double2 *__restrict__ twM, int hl)
+__device__ __forceinline__ void fft256_half(double2 (&z)[8], double2 *ex, const double2 *tw1 /* [7][32]: W256^(l k) */, const double2 *tw2 /* [7][4]: W32^(c k) */, int hl)
 {
     dft8_f64(z);
 #pragma unroll
-    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[hl * k]);
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], tw1[(k - 1) * 32 + hl]);
 #pragma unroll
     for (int k = 0; k < 8; k++) ex[36 * k + hl] = z[k];
     wave_sync();
@@ -291,7 +292,7 @@ __device__ __forceinline__ void fft256_half(double2 (&z)[8], double2 *ex, const 
     wave_sync();
     dft8_f64(z);
 #pragma unroll
-    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], twM[8 * c * k]);
+    for (int k = 1; k < 8; k++) z[k] = cmul_f64(z[k], tw2[(k - 1) * 4 + c]);
 #pragma unroll
     for (int k = 0; k < 8; k++) ex[66 * c + k0 + 8 * k] = z[k];
     wave_sync();
@@ -325,7 +326,7 @@ template <int W> __device__ __forceinline__ double group_max_f64(double v)
 // MODE 1: N = 1024, one frame per wavefront, register-resident transform.
 // MODE 2: N = 512 (16 kHz at the reference's 150 Hz floor, Code/audioPipeline.py:329), TWO frames per
 //         wavefront (one per 32-lane half), register-resident transform.
-template <int WPB, int MODE>
+template <int WPB, int MODE, bool TABS>
 __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const int16_t *__restrict__ pcm, const PiSlice *__restrict__ slices, const PiWork *__restrict__ work, int n_work,
     PiParams P, const double *__restrict__ window, const double *__restrict__ windowR,
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const long long *acc_sum, const int *acc_hi, const int *acc_lo, size_t acc_stride,
     double *__restrict__ cand /* [frames][32]: 16 freq, 16 strength */, int *__restrict__ ncand, double *__restrict__ intensity,
     double *__restrict__ rr_out /* [frames][rr_len] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
-    unsigned int list_cap, int dbg)
+    unsigned int list_cap, int dbg, const double *__restrict__ blob /* register paths: lane-ordered twiddles, twN, window, windowR */)
 {
     constexpr int LW = MODE == 2 ? 32 : 64;              // lanes per frame
     constexpr int FPW = 64 / LW;                         // frames per wavefront
@@ -355,6 +356,35 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     double2 *bufA = MODE == 0 ? wave_base : wave_base + half * REG_C;
     double2 *bufB = bufA + P.zlen;                      // (MODE 0 only)
     double *xr = reinterpret_cast<double *>(bufA);      // MODE 0: real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
+    // register paths: the tables (optionally) and the samples under this work item's frames go to LDS once
+    // per workgroup -- per-lane 2-byte and gather loads were the bottleneck (vector-memory issue, not bytes)
+    const double2 *tw1 = nullptr, *tw2 = nullptr, *twR = nullptr;
+    const double *win = nullptr, *winR = nullptr;
+    const int16_t *spcm = nullptr;
+    int64_t lo = 0;
+    if constexpr (MODE != 0) {
+        double *tab = lds + WPB * R_WAVE_F64;
+        if constexpr (TABS) {
+            for (int i = (int)threadIdx.x; i < (P.blob_f64 >> 1); i += 64 * WPB)
+                reinterpret_cast<double2 *>(tab)[i] = reinterpret_cast<const double2 *>(blob)[i];
+            tw1 = reinterpret_cast<const double2 *>(tab); tw2 = reinterpret_cast<const double2 *>(tab + P.o_tw2);
+            twR = reinterpret_cast<const double2 *>(tab + P.o_twN); win = tab + P.o_win; winR = tab + P.o_winR;
+        } else {
+            tw1 = reinterpret_cast<const double2 *>(blob); tw2 = reinterpret_cast<const double2 *>(blob + P.o_tw2);
+            twR = reinterpret_cast<const double2 *>(blob + P.o_twN); win = blob + P.o_win; winR = blob + P.o_winR;
+        }
+        int16_t *sp = reinterpret_cast<int16_t *>(tab + (TABS ? P.blob_f64 : 0));
+        const double tA = s.t1 + (double)wk.frame0 * P.dt;
+        lo = (int64_t)floor((tA - s.x1) / P.dx) + 1 - P.hw;       // window start of the first frame (slice-relative)
+        for (int i = (int)threadIdx.x; i < P.pcm_span; i += 64 * WPB) {
+            const int64_t rel = lo + i, cc = s.begin + rel;
+            int v = 0;
+            if (rel >= 0 && rel < s.nx && cc >= 0 && cc < s.clip_len) v = (int)pcm[s.clip_off + cc];
+            sp[i] = (int16_t)v;
+        }
+        spcm = sp;
+        __syncthreads();
+    }
     for (int fi = wv * FPW; fi < FPB; fi += WPB * FPW) {
     const int iframe = wk.frame0 + fi + half;           // 0-based
     const bool live = iframe < s.n_frames;
@@ -394,8 +424,8 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
                 const int j = 2 * (hl + LW * r) + h;
                 int x = 0;
                 if (live && j < P.nw) {
-                    const int64_t rel = ws + j, cc = s.begin + rel;
-                    if (rel >= 0 && rel < s.nx && cc >= 0 && cc < s.clip_len) x = (int)pcm[s.clip_off + cc];
+                    const int64_t rel = ws + j;
+                    x = (int)spcm[(int)(ws - lo) + j];
                     if (rel >= m0 && rel <= m1) isum += x;
                 }
                 v[2 * r + h] = x;
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
                 const int j = 2 * (hl + LW * r) + h;
                 f[h] = 0.0;
                 if (live && j < P.nw) {
-                    f[h] = ((double)v[2 * r + h] / 32768.0 - localMean) * window[j];
+                    f[h] = ((double)v[2 * r + h] / 32768.0 - localMean) * win[j];
                     if (j + 1 >= pk0 && j + 1 <= pk1) lpk = fmax(lpk, fabs(f[h]));
                 }
             }
@@ -449,7 +479,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     if (__ballot(active) != 0) {
         if constexpr (MODE != 0) {
             wave_sync();
-            if constexpr (MODE == 1) fft512_reg(z, bufA, twM, lane); else fft256_half(z, bufA, twM, hl);
+            if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
             // power spectrum of the real frame, re-tangled for the second transform.  Lane-local form of
             // the pairwise loop of MODE 0: for every own k, with zm = Z[M - k],
             // X[k] = ez + t, X[M - k]* = ez - t, and W[k] = (e - d sin, -d cos) holds for all k in [0, M).
@@ -460,7 +490,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
             for (int r = 0; r < 8; r++) {
                 const int k = hl + LW * r;
                 const double2 zk = z[r], zm = bufA[(MR - k) & (MR - 1)];
-                const double2 w = twN[k];                                     // (cos, -sin)
+                const double2 w = twR[k];                                     // (cos, -sin)
                 const double2 ez = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
                 const double2 oz = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
                 const double2 t = cmul_f64(oz, w);
@@ -470,7 +500,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
                 z[r] = make_double2(e - d * (-w.y), -(d * w.x));
             }
             wave_sync();
-            if constexpr (MODE == 1) fft512_reg(z, bufA, twM, lane); else fft256_half(z, bufA, twM, hl);
+            if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
             // ac[2n] = Re Y[n], ac[2n+1] = -Im Y[n]; r[k] = ac[k] / (ac[0] windowR[k]) into the same region
             rr = reinterpret_cast<double *>(bufA);
             const double ac0 = __shfl(z[0].x, lane & ~(LW - 1), 64);
@@ -478,8 +508,8 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int k = 2 * (hl + LW * r);
-                    if (k >= 1 && k <= P.bix) { const double v = z[r].x / (ac0 * windowR[k]); rr[P.bix + k] = v; rr[P.bix - k] = v; }
-                    if (k + 1 <= P.bix) { const double v = -z[r].y / (ac0 * windowR[k + 1]); rr[P.bix + k + 1] = v; rr[P.bix - k - 1] = v; }
+                    if (k >= 1 && k <= P.bix) { const double v = z[r].x / (ac0 * winR[k]); rr[P.bix + k] = v; rr[P.bix - k] = v; }
+                    if (k + 1 <= P.bix) { const double v = -z[r].y / (ac0 * winR[k + 1]); rr[P.bix + k + 1] = v; rr[P.bix - k - 1] = v; }
                 }
                 if (hl == 0) rr[P.bix] = 1.0;
             }
@@ -1172,6 +1202,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                      : (nfft == 1024 && P.rr_len <= R_WAVE_F64) ? 1
                      : (nfft == 512 && P.rr_len <= R_WAVE_F64 / 2) ? 2 : 0;
             P.fpb = P.mode == 2 ? 2 * PI_FPB : PI_FPB;
+            P.tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) != 0 : P.mode == 2;
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
             for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
@@ -1183,6 +1214,28 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             PCE_HIP(c, c->pi_windowR.reserve(sizeof(double) * windowR.size()));
             PCE_HIP(c, hipMemcpyAsync(c->pi_window.p, window.data(), sizeof(double) * window.size(), hipMemcpyHostToDevice, c->stream));
             PCE_HIP(c, hipMemcpyAsync(c->pi_windowR.p, windowR.data(), sizeof(double) * windowR.size(), hipMemcpyHostToDevice, c->stream));
+            std::vector<double> blob;
+            if (P.mode != 0) {
+                // lane-ordered tables for the register paths: tw1[k-1][l] = W_M^(l k), tw2[k-1][c] = W_M^(8 c k),
+                // twN[k] = W_N^k (k < M), window, windowR[0..bix]; every table starts on a 16-byte boundary
+                const int LW = P.mode == 2 ? 32 : 64, CW = LW / 8;
+                auto W = [&](int m, int period) { return std::pair<double, double>(std::cos(2.0 * PI_D * m / period), -std::sin(2.0 * PI_D * m / period)); };
+                for (int k = 1; k < 8; k++) for (int l = 0; l < LW; l++) { auto w = W(l * k, Mc); blob.push_back(w.first); blob.push_back(w.second); }
+                P.o_tw2 = (int)blob.size();
+                for (int k = 1; k < 8; k++) for (int q = 0; q < CW; q++) { auto w = W(8 * q * k, Mc); blob.push_back(w.first); blob.push_back(w.second); }
+                P.o_twN = (int)blob.size();
+                for (int k = 0; k < Mc; k++) { auto w = W(k, nfft); blob.push_back(w.first); blob.push_back(w.second); }
+                P.o_win = (int)blob.size();
+                for (int j = 0; j < P.nw; j++) blob.push_back(window[(size_t)j]);
+                if (blob.size() & 1) blob.push_back(0.0);
+                P.o_winR = (int)blob.size();
+                for (int k = 0; k <= P.bix; k++) blob.push_back(windowR[(size_t)k]);
+                if (blob.size() & 1) blob.push_back(0.0);
+                P.blob_f64 = (int)blob.size();
+                P.pcm_span = (((int)std::ceil((double)(P.fpb - 1) * P.dt / P.dx) + P.nw + 4) + 7) & ~7;
+                PCE_HIP(c, c->pi_blob.reserve(sizeof(double) * blob.size()));
+                PCE_HIP(c, hipMemcpyAsync(c->pi_blob.p, blob.data(), sizeof(double) * blob.size(), hipMemcpyHostToDevice, c->stream));
+            }
             PCE_HIP(c, hipStreamSynchronize(c->stream));
         }
         static_assert(sizeof(PiParams) <= sizeof(c->pi_P), "PiParams storage");
@@ -1249,12 +1302,13 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             int wpb = PI_WPB;
             while (wpb > 1 && sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb > 160 * 1024) wpb >>= 1;
             if (P.mode != 0) wpb = PI_WPB;
-            const size_t lds = P.mode != 0 ? sizeof(double) * (size_t)R_WAVE_F64 * PI_WPB : sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb;
-            const void *kfn = P.mode == 1 ? reinterpret_cast<const void *>(k_pitch_frames<4, 1>)
-                              : P.mode == 2 ? reinterpret_cast<const void *>(k_pitch_frames<4, 2>)
-                              : wpb == 4 ? reinterpret_cast<const void *>(k_pitch_frames<4, 0>)
-                              : wpb == 2 ? reinterpret_cast<const void *>(k_pitch_frames<2, 0>)
-                                         : reinterpret_cast<const void *>(k_pitch_frames<1, 0>);
+            const size_t lds = P.mode != 0 ? sizeof(double) * ((size_t)R_WAVE_F64 * PI_WPB + (P.tabs ? (size_t)P.blob_f64 : 0)) + sizeof(int16_t) * (size_t)P.pcm_span
+                                           : sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb;
+            const void *kfn = P.mode == 1 ? (P.tabs ? reinterpret_cast<const void *>(k_pitch_frames<4, 1, true>) : reinterpret_cast<const void *>(k_pitch_frames<4, 1, false>))
+                              : P.mode == 2 ? (P.tabs ? reinterpret_cast<const void *>(k_pitch_frames<4, 2, true>) : reinterpret_cast<const void *>(k_pitch_frames<4, 2, false>))
+                              : wpb == 4 ? reinterpret_cast<const void *>(k_pitch_frames<4, 0, false>)
+                              : wpb == 2 ? reinterpret_cast<const void *>(k_pitch_frames<2, 0, false>)
+                                         : reinterpret_cast<const void *>(k_pitch_frames<1, 0, false>);
             if (lds > 64 * 1024)
                 PCE_HIP(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const size_t cnt_bytes = sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE;
@@ -1270,13 +1324,15 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                                        c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
                                        c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
                                        c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap,
-                                       getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0);
+                                       getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0, c->pi_blob.as<double>());
                 };
-                if (P.mode == 1) launch(k_pitch_frames<4, 1>);
-                else if (P.mode == 2) launch(k_pitch_frames<4, 2>);
-                else if (wpb == 4) launch(k_pitch_frames<4, 0>);
-                else if (wpb == 2) launch(k_pitch_frames<2, 0>);
-                else launch(k_pitch_frames<1, 0>);
+                if (P.mode == 1 && P.tabs) launch(k_pitch_frames<4, 1, true>);
+                else if (P.mode == 1) launch(k_pitch_frames<4, 1, false>);
+                else if (P.mode == 2 && P.tabs) launch(k_pitch_frames<4, 2, true>);
+                else if (P.mode == 2) launch(k_pitch_frames<4, 2, false>);
+                else if (wpb == 4) launch(k_pitch_frames<4, 0, false>);
+                else if (wpb == 2) launch(k_pitch_frames<2, 0, false>);
+                else launch(k_pitch_frames<1, 0, false>);
             }
             {
                 KernelTimer t(c, PCE_K_PITCH_REFINE);
