@@ -646,11 +646,13 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
 
 // ---------------------------------------------------------------------------
 // k_pitch_refine: Praat's second pass (NUMimproveMaximum, sinc depth 70/700) over the flat
-// list of candidates.  Sixteen lanes per candidate: the 144 autocorrelation values a
-// depth-70 interpolation can touch live in registers (9 per lane, fixed absolute indices),
-// the per-evaluation scalars (Brent state, sin) are shared by four candidates per wave, and
-// the 16-lane sums use DPP row operations (no LDS).  Trigonometry is evaluated with plain
-// polynomials: every argument is known to lie in (0, pi].
+// list of candidates.  Eight lanes per candidate: the 144 autocorrelation values a
+// depth-70 interpolation can touch live in registers (18 per lane, fixed absolute indices),
+// the per-evaluation scalars (Brent state, sin) are shared by eight candidates per wave, and
+// the 8-lane sums use DPP row operations (no LDS).  Trigonometry is evaluated with plain
+// polynomials (every argument is known to lie in (0, pi]); along a lane's rows the raised-cosine
+// arguments form an arithmetic progression, so only the two rows nearest x on each side take
+// the polynomial and the rest follow by the three-term cosine recurrence.
 // ---------------------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
 {
@@ -666,6 +668,14 @@ __device__ __forceinline__ double row_sum16(double v)
     v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
     v += dpp_f64<0x141>(v);    // row_half_mirror
     v += dpp_f64<0x140>(v);    // row_mirror
+    return v;
+}
+// sum over the 8 lanes of half a DPP row
+__device__ __forceinline__ double row_sum8(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
     return v;
 }
 // cos(h) and sin(h) for h in [0, pi/2] (Taylor about 0; truncation < 1e-19)
@@ -714,26 +724,27 @@ __device__ __forceinline__ double rcp_f64(double a)
 }
 
 // NUM_interpolate_sinc for a depth that stays inside the register window.
-// yv[m] = y[wbase + l16 + 16 m] (1-based y index); the caller guarantees 3 <= D and that
-// midleft is ixmid-1 or ixmid with wbase = ixmid - 71, so window rows m <= 3 lie left of x,
-// rows m >= 5 right of it and only row 4 straddles it.  Per lane the index distance k
-// changes by 16 from row to row: the (-1)^k sign is one value per side.  sin(pi (1 - t)) is
+// yv[m] = y[wbase + l8 + 8 m] (1-based y index), m < 18; the caller guarantees 8 <= D and that
+// midleft is ixmid-1 or ixmid with wbase = ixmid - 71, so window rows m <= 7 lie left of x,
+// rows m >= 9 right of it and only row 8 straddles it.  Per lane the index distance k
+// changes by 8 from row to row: the (-1)^k sign is one value per side.  sin(pi (1 - t)) is
 // taken equal to sin(pi t) (Praat evaluates both; they differ by rounding only).
-__device__ __forceinline__ double sinc_term(double kd, double a0, double aa0, double daa, double hs, double yv, double dlim)
+// The window factor 1 + cos(aa_k), aa_k = pi (k + frac) / (D + frac), is linear in k: with
+// u_m = 1 + cos(aa0 + m delta), u_(m+1) = tc u_m - u_(m-1) + (2 - tc), tc = 2 cos(delta).
+// Rows are walked outward from x, so a row inside the depth limit only ever depends on rows
+// inside it (rows beyond the limit are discarded by the k < D select, whatever they hold).
+__device__ __forceinline__ double sinc_w(double kd, double a0, double hs, double u)
 {
-    const double a = fma(kd, PI_D, a0);
-    const double aa = fma(kd, daa, aa0);
-    const double w = hs * rcp_f64(a) * one_plus_cos_0pi(aa);
-    return (kd >= 0.0 && kd < dlim) ? yv * w : 0.0;
+    return hs * rcp_f64(fma(kd, PI_D, a0)) * u;
 }
-__device__ __forceinline__ double sinc_group_reg(const double (&yv)[9], int wbase, int ynx, double x, int maxDepth, int l16)
+__device__ __forceinline__ double sinc_group_reg(const double (&yv)[18], int wbase, int ynx, double x, int maxDepth, int l8)
 {
     const int midleft = (int)floor(x), midright = midleft + 1;
     if (x == (double)midleft) {
         double pick = 0.0;
 #pragma unroll
-        for (int m = 0; m < 9; m++) if (wbase + l16 + 16 * m == midleft) pick = yv[m];
-        return row_sum16(pick);
+        for (int m = 0; m < 18; m++) if (wbase + l8 + 8 * m == midleft) pick = yv[m];
+        return row_sum8(pick);
     }
     int D = maxDepth;
     if (D > midright - 1) D = midright - 1;
@@ -745,25 +756,55 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[9], int wbas
     const double rden_l = rcp_f64(x - (double)left + 1.0), rden_r = rcp_f64((double)right - x + 1.0);
     const double aa_l = a_l * rden_l, daa_l = PI_D * rden_l;
     const double aa_r = a_r * rden_r, daa_r = PI_D * rden_r;
-    const int kl0 = midleft - wbase - l16;            // k of row 0 on the left side (decreases by 16 per row)
-    const int kr0 = wbase + l16 - midright;           // k of row 0 on the right side (increases by 16 per row)
+    const int kl0 = midleft - wbase - l8;             // k of row 0 on the left side (decreases by 8 per row)
+    const int kr0 = wbase + l8 - midright;            // k of row 0 on the right side (increases by 8 per row)
     const double hs_l = (kl0 & 1) ? -hs : hs, hs_r = (kr0 & 1) ? -hs : hs;
     const double kdl = (double)kl0, kdr = (double)kr0;
-    double acc = 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; m++) acc += sinc_term(kdl - 16.0 * m, a_l, aa_l, daa_l, hs_l, yv[m], dlim);
-    {   // row 4 holds the lanes around x
+    // rows 0..7 and 9..17 have k >= 0 by construction (wbase = ixmid - 71): only the depth limit can drop them
+    auto keep = [&](double kd, double t) { return kd < dlim ? t : 0.0; };
+    double acc;
+    {   // row 8 holds the lanes around x
         const bool is_left = kl0 - 64 >= 0;
-        acc += sinc_term(is_left ? kdl - 64.0 : kdr + 64.0, is_left ? a_l : a_r, is_left ? aa_l : aa_r, is_left ? daa_l : daa_r,
-                         is_left ? hs_l : hs_r, yv[4], dlim);
+        const double kd = is_left ? kdl - 64.0 : kdr + 64.0;
+        const double u = one_plus_cos_0pi(fma(kd, is_left ? daa_l : daa_r, is_left ? aa_l : aa_r));
+        const double t8 = yv[8] * sinc_w(kd, is_left ? a_l : a_r, is_left ? hs_l : hs_r, u);
+        acc = (kd >= 0.0 && kd < dlim) ? t8 : 0.0;
     }
+    {   // left side, rows 7 (nearest x) .. 0
+        const double cq = cos_q(4.0 * daa_l);                           // cos(delta / 2), delta = 8 daa <= pi
+        const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
+        double u1 = one_plus_cos_0pi(fma(kdl - 56.0, daa_l, aa_l));     // row 7
+        double u0 = one_plus_cos_0pi(fma(kdl - 48.0, daa_l, aa_l));     // row 6
+        acc += keep(kdl - 56.0, yv[7] * sinc_w(kdl - 56.0, a_l, hs_l, u1));
+        acc += keep(kdl - 48.0, yv[6] * sinc_w(kdl - 48.0, a_l, hs_l, u0));
 #pragma unroll
-    for (int m = 5; m < 9; m++) acc += sinc_term(kdr + 16.0 * m, a_r, aa_r, daa_r, hs_r, yv[m], dlim);
-    return row_sum16(acc);
+        for (int m = 5; m >= 0; m--) {
+            const double u = fma(tc, u0, g) - u1;
+            u1 = u0; u0 = u;
+            const double kd = kdl - 8.0 * m;
+            acc += keep(kd, yv[m] * sinc_w(kd, a_l, hs_l, u));
+        }
+    }
+    {   // right side, rows 9 (nearest x) .. 17
+        const double cq = cos_q(4.0 * daa_r);
+        const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
+        double u1 = one_plus_cos_0pi(fma(kdr + 72.0, daa_r, aa_r));     // row 9
+        double u0 = one_plus_cos_0pi(fma(kdr + 80.0, daa_r, aa_r));     // row 10
+        acc += keep(kdr + 72.0, yv[9] * sinc_w(kdr + 72.0, a_r, hs_r, u1));
+        acc += keep(kdr + 80.0, yv[10] * sinc_w(kdr + 80.0, a_r, hs_r, u0));
+#pragma unroll
+        for (int m = 11; m < 18; m++) {
+            const double u = fma(tc, u0, g) - u1;
+            u1 = u0; u0 = u;
+            const double kd = kdr + 8.0 * m;
+            acc += keep(kd, yv[m] * sinc_w(kd, a_r, hs_r, u));
+        }
+    }
+    return row_sum8(acc);
 }
 
 // generic NUM_interpolate_sinc with y in global memory (depth 700, or windows near the array ends)
-__device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x, int maxDepth, int l16)
+__device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x, int maxDepth, int l8)
 {
     const int midleft = (int)floor(x), midright = midleft + 1;
     if (x > (double)ynx) return y[ynx - 1];
@@ -786,7 +827,7 @@ __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x
     const double aa_l = a_l / den_l, daa_l = PI_D / den_l;
     const double aa_r = a_r / den_r, daa_r = PI_D / den_r;
     double acc = 0.0;
-    for (int t = l16; t < 2 * maxDepth; t += 16) {
+    for (int t = l8; t < 2 * maxDepth; t += 8) {
         const bool is_left = t < maxDepth;
         const int k = is_left ? t : t - maxDepth;
         const double kd = (double)k;
@@ -797,88 +838,106 @@ __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x
         const int ix = is_left ? midleft - k : midright + k;
         acc += y[ix - 1] * (hs * rcp_f64(a) * one_plus_cos_0pi(aa));
     }
-    return row_sum16(acc);
+    return row_sum8(acc);
 }
 
 __global__ __launch_bounds__(256) void k_pitch_refine(PiParams P, const double *__restrict__ rr_in, const RefineItem *__restrict__ items,
                                                      const unsigned int *__restrict__ item_count, unsigned int list_cap,
                                                      double *__restrict__ cand)
 {
-    const int l16 = threadIdx.x & 15;
-    const unsigned int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l8 = threadIdx.x & 7;
+    const unsigned int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     const unsigned int list = gid & (RF_LISTS - 1);
     const unsigned int group = gid / RF_LISTS;
-    const unsigned int n_groups = ((gridDim.x * blockDim.x) >> 4) / RF_LISTS;
+    const unsigned int n_groups = ((gridDim.x * blockDim.x) >> 3) / RF_LISTS;
     const unsigned int count = item_count[list * RF_CSTRIDE];
     items += (size_t)list * list_cap;
     const int ynx = 2 * P.bix + 1;
     const double golden = 1.0 - 0.6180339887498948482045868343656381177203;
     const double sqrt_epsilon = 1.4901161193847656e-08;
     const double tol = 1e-10;
-    for (unsigned int it = group; it < count; it += n_groups) {
-        const RefineItem item = items[it];
-        const double *y = rr_in + item.frame * (long long)P.rr_len;     // y[i-1] = Praat's y[i]
-        const int ixmid = item.imax + P.bix + 1;
-        // depth choice uses the first-pass (parabolic) frequency, as Praat does
-        const double r0 = y[ixmid - 1], rm = y[ixmid - 2], rp = y[ixmid];
-        const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
-        const double f1 = 1.0 / P.dx / ((double)item.imax + dr / d2r);
-        const int depth = f1 > 0.3 / P.dx ? 700 : 70;
-        double xres, yres;
-        if (ixmid <= 1) { xres = 1.0; yres = y[0]; }
-        else if (ixmid >= ynx) { xres = (double)ynx; yres = y[ynx - 1]; }
-        else {
-            // the register window serves midleft in {ixmid-1, ixmid}: needs depth <= 70 and D >= 3 for both
-            const bool fast = depth == 70 && ixmid - 1 >= 4 && ynx - ixmid >= 3;
-            const int wbase = ixmid - 71;
-            double yv[9];
+    auto finish = [&](const RefineItem &item, double xres, double yres) {
+        xres -= (double)(P.bix + 1);
+        if (yres > 1.0) yres = 1.0 / yres;
+        if (l8 == 0) {
+            cand[item.frame * 32 + item.slot] = 1.0 / P.dx / xres;
+            cand[item.frame * 32 + 16 + item.slot] = yres;
+        }
+    };
+    // Brent's minimiser (Praat NUMminimize_brent on -sinc) as a state machine: every trip of the loop
+    // is ONE function evaluation for each of the wave's eight candidates, and a group whose candidate
+    // has converged fetches its next item at once, so candidates with different iteration counts do not
+    // wait for one another.  The iterates are those of the sequential loop.
+    unsigned int it = group;
+    bool have = false;
+    RefineItem item = {0, 0, 0};
+    const double *y = rr_in;
+    int wbase = 0, depth = 70, iter = 0;
+    bool fast = false;
+    double yv[18];
+    double a = 0.0, b = 0.0, v = 0.0, w = 0.0, x = 0.0, fv = 0.0, fw = 0.0, fx = 0.0, t = 0.0;
+    for (;;) {
+        while (!have && it < count) {
+            item = items[it];
+            it += n_groups;
+            y = rr_in + item.frame * (long long)P.rr_len;                // y[i-1] = Praat's y[i]
+            const int ixmid = item.imax + P.bix + 1;
+            if (ixmid <= 1) { finish(item, 1.0, y[0]); continue; }
+            if (ixmid >= ynx) { finish(item, (double)ynx, y[ynx - 1]); continue; }
+            // depth choice uses the first-pass (parabolic) frequency, as Praat does
+            const double r0 = y[ixmid - 1], rm = y[ixmid - 2], rp = y[ixmid];
+            const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
+            const double f1 = 1.0 / P.dx / ((double)item.imax + dr / d2r);
+            depth = f1 > 0.3 / P.dx ? 700 : 70;
+            // the register window serves midleft in {ixmid-1, ixmid}: needs depth <= 70 and D >= 8 for both
+            fast = depth == 70 && ixmid - 1 >= 9 && ynx - ixmid >= 8;
+            wbase = ixmid - 71;
 #pragma unroll
-            for (int m = 0; m < 9; m++) {
-                const int ix = wbase + l16 + 16 * m;
+            for (int m = 0; m < 18; m++) {
+                const int ix = wbase + l8 + 8 * m;
                 yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[ix - 1] : 0.0;
             }
-            auto eval = [&](double xx) -> double {
-                return fast ? -sinc_group_reg(yv, wbase, ynx, xx, 70, l16) : -sinc_group_mem(y, ynx, xx, depth, l16);
-            };
-            double a = (double)(ixmid - 1), b = (double)(ixmid + 1);
-            double v = a + golden * (b - a);
-            double fv = eval(v);
-            double x = v, w = v, fx = fv, fw = fv;
-            for (int iter = 1; iter <= 60; iter++) {
+            a = (double)(ixmid - 1); b = (double)(ixmid + 1);
+            v = a + golden * (b - a);
+            t = v; iter = 0; have = true;
+        }
+        if (__ballot(have) == 0) break;
+        if (have) {
+            const double ft = fast ? -sinc_group_reg(yv, wbase, ynx, t, 70, l8) : -sinc_group_mem(y, ynx, t, depth, l8);
+            if (iter == 0) {
+                x = v; w = v; fx = ft; fw = ft; fv = ft;
+            } else if (ft <= fx) {
+                if (t < x) b = x; else a = x;
+                v = w; w = x; x = t;
+                fv = fw; fw = fx; fx = ft;
+            } else {
+                if (t < x) a = t; else b = t;
+                if (ft <= fw || w == x) { v = w; w = t; fv = fw; fw = ft; }
+                else if (ft <= fv || v == x || v == w) { v = t; fv = ft; }
+            }
+            iter++;
+            bool done = iter > 60;
+            if (!done) {
                 const double range = b - a;
                 const double middle_range = (a + b) / 2.0;
                 const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.0;
-                if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) break;
-                double new_step = golden * (x < middle_range ? b - x : a - x);
-                if (fabs(x - w) >= tol_act) {
-                    double t = (x - w) * (fx - fv);
-                    double q = (x - v) * (fx - fw);
-                    double p = (x - v) * q - (x - w) * t;
-                    q = 2.0 * (q - t);
-                    if (q > 0.0) p = -p; else q = -q;
-                    if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
-                        new_step = p / q;
-                }
-                if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
-                const double t = x + new_step;
-                const double ft = eval(t);
-                if (ft <= fx) {
-                    if (t < x) b = x; else a = x;
-                    v = w; w = x; x = t;
-                    fv = fw; fw = fx; fx = ft;
-                } else {
-                    if (t < x) a = t; else b = t;
-                    if (ft <= fw || w == x) { v = w; w = t; fv = fw; fw = ft; }
-                    else if (ft <= fv || v == x || v == w) { v = t; fv = ft; }
+                if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) done = true;
+                else {
+                    double new_step = golden * (x < middle_range ? b - x : a - x);
+                    if (fabs(x - w) >= tol_act) {
+                        double tt = (x - w) * (fx - fv);
+                        double q = (x - v) * (fx - fw);
+                        double p = (x - v) * q - (x - w) * tt;
+                        q = 2.0 * (q - tt);
+                        if (q > 0.0) p = -p; else q = -q;
+                        if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
+                            new_step = p / q;
+                    }
+                    if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
+                    t = x + new_step;
                 }
             }
-            xres = x; yres = -fx;
-        }
-        xres -= (double)(P.bix + 1);
-        if (yres > 1.0) yres = 1.0 / yres;
-        if (l16 == 0) {
-            cand[item.frame * 32 + item.slot] = 1.0 / P.dx / xres;
-            cand[item.frame * 32 + 16 + item.slot] = yres;
+            if (done) { finish(item, x, -fx); have = false; }
         }
     }
 }
