@@ -161,6 +161,13 @@ __device__ double sinc_wave(const double *y, int nx, double x, int maxDepth, int
 // (NUMfft_forward / power / NUMfft_backward in Sound_to_Pitch.cpp); N = nsampFFT.
 // LDS index padding: one complex per 8 keeps the stride-4 Stockham stores conflict-free.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_f64(double a)
+{
+    // v_rcp_f64 is good to 2^-24 (measured 4.6e-8); one cubic step r (1 + e + e^2) leaves e^3 ~ 1e-22
+    const double r = __builtin_amdgcn_rcp(a);
+    const double e = fma(-a, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
 __device__ __forceinline__ int ZP(int p) { return p + (p >> 3); }
 __device__ __forceinline__ double2 cmul_f64(double2 a, double2 w)
 {
@@ -502,14 +509,15 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
             wave_sync();
             if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
             // ac[2n] = Re Y[n], ac[2n+1] = -Im Y[n]; r[k] = ac[k] / (ac[0] windowR[k]) into the same region
+            // (reciprocal to < 1 ulp and a multiply: the quotient is not correctly rounded, like the transforms before it)
             rr = reinterpret_cast<double *>(bufA);
             const double ac0 = __shfl(z[0].x, lane & ~(LW - 1), 64);
             if (active) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int k = 2 * (hl + LW * r);
-                    if (k >= 1 && k <= P.bix) { const double v = z[r].x / (ac0 * winR[k]); rr[P.bix + k] = v; rr[P.bix - k] = v; }
-                    if (k + 1 <= P.bix) { const double v = -z[r].y / (ac0 * winR[k + 1]); rr[P.bix + k + 1] = v; rr[P.bix - k - 1] = v; }
+                    if (k >= 1 && k <= P.bix) { const double v = z[r].x * rcp_f64(ac0 * winR[k]); rr[P.bix + k] = v; rr[P.bix - k] = v; }
+                    if (k + 1 <= P.bix) { const double v = -z[r].y * rcp_f64(ac0 * winR[k + 1]); rr[P.bix + k + 1] = v; rr[P.bix - k - 1] = v; }
                 }
                 if (hl == 0) rr[P.bix] = 1.0;
             }
@@ -678,50 +686,38 @@ __device__ __forceinline__ double row_sum8(double v)
     v += dpp_f64<0x141>(v);
     return v;
 }
-// cos(h) and sin(h) for h in [0, pi/2] (Taylor about 0; truncation < 1e-19)
+// cos(h) and sin(h) for h in [0, pi/2] (Taylor about 0; truncation < 1e-19), evaluated by Estrin's
+// scheme: a dependent fp64 FMA costs ~30 cycles on this part (measured), so the 13-deep Horner chain
+// was the critical path of every evaluation; this form is 5 deep for two more multiplies.
+__device__ __forceinline__ double poly13_estrin(double z, double c0, double c1, double c2, double c3, double c4, double c5, double c6,
+                                                double c7, double c8, double c9, double c10, double c11, double c12)
+{
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double q0 = fma(c1, z, c0), q1 = fma(c3, z, c2), q2 = fma(c5, z, c4), q3 = fma(c7, z, c6), q4 = fma(c9, z, c8), q5 = fma(c11, z, c10);
+    const double r0 = fma(q1, z2, q0), r1 = fma(q3, z2, q2), r2 = fma(q5, z2, q4);
+    const double s0 = fma(r1, z4, r0), s1 = fma(c12, z4, r2);
+    return fma(s1, z8, s0);
+}
 __device__ __forceinline__ double cos_q(double h)
 {
-    const double z = h * h;
-    double p = 1.6117375710961184e-24;                 // 1/24!
-    p = fma(p, z, -8.8967913924505741e-22);            // -1/22!
-    p = fma(p, z, 4.1103176233121648e-19);
-    p = fma(p, z, -1.5619206968586225e-16);
-    p = fma(p, z, 4.7794773323873853e-14);
-    p = fma(p, z, -1.1470745597729725e-11);
-    p = fma(p, z, 2.0876756987868099e-09);
-    p = fma(p, z, -2.7557319223985888e-07);
-    p = fma(p, z, 2.4801587301587302e-05);
-    p = fma(p, z, -1.3888888888888889e-03);
-    p = fma(p, z, 4.1666666666666664e-02);
-    p = fma(p, z, -0.5);
-    return fma(p, z, 1.0);
+    return poly13_estrin(h * h, 1.0, -0.5, 4.1666666666666664e-02, -1.3888888888888889e-03, 2.4801587301587302e-05, -2.7557319223985888e-07,
+                         2.0876756987868099e-09, -1.1470745597729725e-11, 4.7794773323873853e-14, -1.5619206968586225e-16,
+                         4.1103176233121648e-19, -8.8967913924505741e-22, 1.6117375710961184e-24);
 }
 __device__ __forceinline__ double sin_q(double h)
 {
+    // sin h = h + h z (s0 + s1 z + ... + s11 z^11), z = h^2
     const double z = h * h;
-    double p = -3.8681701706306841e-23;                // -1/23!
-    p = fma(p, z, 1.9572941063391263e-20);
-    p = fma(p, z, -8.2206352466243295e-18);
-    p = fma(p, z, 2.8114572543455206e-15);
-    p = fma(p, z, -7.6471637318198164e-13);
-    p = fma(p, z, 1.6059043836821613e-10);
-    p = fma(p, z, -2.5052108385441720e-08);
-    p = fma(p, z, 2.7557319223985893e-06);
-    p = fma(p, z, -1.9841269841269841e-04);
-    p = fma(p, z, 8.3333333333333332e-03);
-    p = fma(p, z, -1.6666666666666666e-01);
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double q0 = fma(8.3333333333333332e-03, z, -1.6666666666666666e-01), q1 = fma(2.7557319223985893e-06, z, -1.9841269841269841e-04);
+    const double q2 = fma(1.6059043836821613e-10, z, -2.5052108385441720e-08), q3 = fma(2.8114572543455206e-15, z, -7.6471637318198164e-13);
+    const double q4 = fma(1.9572941063391263e-20, z, -8.2206352466243295e-18), q5 = -3.8681701706306841e-23;
+    const double r0 = fma(q1, z2, q0), r1 = fma(q3, z2, q2), r2 = fma(q5, z2, q4);
+    const double p = fma(r2, z8, fma(r1, z4, r0));
     return fma(p * z, h, h);
 }
 __device__ __forceinline__ double sin_0pi(double a) { const double h = 0.5 * a; return 2.0 * sin_q(h) * cos_q(h); }
 __device__ __forceinline__ double one_plus_cos_0pi(double a) { const double c = cos_q(0.5 * a); return 2.0 * c * c; }
-__device__ __forceinline__ double rcp_f64(double a)
-{
-    double r = __builtin_amdgcn_rcp(a);
-    double e = fma(-a, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-a, r, 1.0);
-    return fma(r, e, r);
-}
 
 // NUM_interpolate_sinc for a depth that stays inside the register window.
 // yv[m] = y[wbase + l8 + 8 m] (1-based y index), m < 18; the caller guarantees 8 <= D and that
@@ -733,9 +729,9 @@ __device__ __forceinline__ double rcp_f64(double a)
 // u_m = 1 + cos(aa0 + m delta), u_(m+1) = tc u_m - u_(m-1) + (2 - tc), tc = 2 cos(delta).
 // Rows are walked outward from x, so a row inside the depth limit only ever depends on rows
 // inside it (rows beyond the limit are discarded by the k < D select, whatever they hold).
-__device__ __forceinline__ double sinc_w(double kd, double a0, double hs, double u)
+__device__ __forceinline__ double sinc_w(double kd, double a0, double yu /* y (1 + cos) */)
 {
-    return hs * rcp_f64(fma(kd, PI_D, a0)) * u;
+    return yu * rcp_f64(fma(kd, PI_D, a0));         // the side's +-0.5 sin factor is applied once per side
 }
 __device__ __forceinline__ double sinc_group_reg(const double (&yv)[18], int wbase, int ynx, double x, int maxDepth, int l8)
 {
@@ -767,7 +763,7 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[18], int wba
         const bool is_left = kl0 - 64 >= 0;
         const double kd = is_left ? kdl - 64.0 : kdr + 64.0;
         const double u = one_plus_cos_0pi(fma(kd, is_left ? daa_l : daa_r, is_left ? aa_l : aa_r));
-        const double t8 = yv[8] * sinc_w(kd, is_left ? a_l : a_r, is_left ? hs_l : hs_r, u);
+        const double t8 = (is_left ? hs_l : hs_r) * sinc_w(kd, is_left ? a_l : a_r, yv[8] * u);
         acc = (kd >= 0.0 && kd < dlim) ? t8 : 0.0;
     }
     {   // left side, rows 7 (nearest x) .. 0
@@ -775,30 +771,32 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[18], int wba
         const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
         double u1 = one_plus_cos_0pi(fma(kdl - 56.0, daa_l, aa_l));     // row 7
         double u0 = one_plus_cos_0pi(fma(kdl - 48.0, daa_l, aa_l));     // row 6
-        acc += keep(kdl - 56.0, yv[7] * sinc_w(kdl - 56.0, a_l, hs_l, u1));
-        acc += keep(kdl - 48.0, yv[6] * sinc_w(kdl - 48.0, a_l, hs_l, u0));
+        double side = keep(kdl - 56.0, sinc_w(kdl - 56.0, a_l, yv[7] * u1));
+        side += keep(kdl - 48.0, sinc_w(kdl - 48.0, a_l, yv[6] * u0));
 #pragma unroll
         for (int m = 5; m >= 0; m--) {
-            const double u = fma(tc, u0, g) - u1;
+            const double u = fma(tc, u0, g - u1);        // (g - u1) is off the critical path
             u1 = u0; u0 = u;
             const double kd = kdl - 8.0 * m;
-            acc += keep(kd, yv[m] * sinc_w(kd, a_l, hs_l, u));
+            side += keep(kd, sinc_w(kd, a_l, yv[m] * u));
         }
+        acc = fma(hs_l, side, acc);
     }
     {   // right side, rows 9 (nearest x) .. 17
         const double cq = cos_q(4.0 * daa_r);
         const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
         double u1 = one_plus_cos_0pi(fma(kdr + 72.0, daa_r, aa_r));     // row 9
         double u0 = one_plus_cos_0pi(fma(kdr + 80.0, daa_r, aa_r));     // row 10
-        acc += keep(kdr + 72.0, yv[9] * sinc_w(kdr + 72.0, a_r, hs_r, u1));
-        acc += keep(kdr + 80.0, yv[10] * sinc_w(kdr + 80.0, a_r, hs_r, u0));
+        double side = keep(kdr + 72.0, sinc_w(kdr + 72.0, a_r, yv[9] * u1));
+        side += keep(kdr + 80.0, sinc_w(kdr + 80.0, a_r, yv[10] * u0));
 #pragma unroll
         for (int m = 11; m < 18; m++) {
-            const double u = fma(tc, u0, g) - u1;
+            const double u = fma(tc, u0, g - u1);        // (g - u1) is off the critical path
             u1 = u0; u0 = u;
             const double kd = kdr + 8.0 * m;
-            acc += keep(kd, yv[m] * sinc_w(kd, a_r, hs_r, u));
+            side += keep(kd, sinc_w(kd, a_r, yv[m] * u));
         }
+        acc = fma(hs_r, side, acc);
     }
     return row_sum8(acc);
 }
@@ -841,7 +839,7 @@ __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x
     return row_sum8(acc);
 }
 
-__global__ __launch_bounds__(256) void k_pitch_refine(PiParams P, const double *__restrict__ rr_in, const RefineItem *__restrict__ items,
+__global__ __launch_bounds__(256, 3) void k_pitch_refine(PiParams P, const double *__restrict__ rr_in, const RefineItem *__restrict__ items,
                                                      const unsigned int *__restrict__ item_count, unsigned int list_cap,
                                                      double *__restrict__ cand)
 {
@@ -1395,7 +1393,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             }
             {
                 KernelTimer t(c, PCE_K_PITCH_REFINE);
-                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 8u;
+                // 3 workgroups per CU are resident (168 VGPRs); 24 per CU measured best (1.30 ms against 1.47 at 3: the lists are uneven)
+                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (getenv("PCE_K2_BPC") ? (unsigned)atoi(getenv("PCE_K2_BPC")) : 24u);
                 hipLaunchKernelGGL(k_pitch_refine, dim3(blocks), dim3(256), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
                                    list_cap, c->pi_cand.as<double>());
             }
