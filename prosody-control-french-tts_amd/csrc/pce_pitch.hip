@@ -76,7 +76,6 @@ constexpr double LOG2E_D = 1.4426950408889634073599246810018921374266;
 constexpr int PI_WPB = 4;                 // waves per block in k_pitch_frames
 constexpr int PI_FPB = 4;                 // frames per work item (one per wave measured fastest: silent frames exit early)
 constexpr int PI_MAXC = 16;               // candidates per frame the kernels can hold
-constexpr int PATH_TILE = 64;
 constexpr int RF_LISTS = 256;             // independent candidate lists (one hot counter would serialise in L2)
 constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte lines             // frames staged per LDS tile in k_pitch_path
 
@@ -947,7 +946,7 @@ constexpr int BT_TILE = 256;              // frames per back-tracking tile
 constexpr int RUN_LISTS = 64;             // independent run lists (see RF_LISTS)
 constexpr double PATH_VOICELESS = 1e300;
 
-struct PathRun { long long frame; int slice; int pad; };
+struct PathRun { long long frame; long long gend; int has_prev; int pad; };   // run start, slice end (global frame indices), a cut frame precedes
 
 __device__ __forceinline__ double readlane_f64(double v, int src)
 {
@@ -990,7 +989,7 @@ __global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const PiSlice *
             if (li == 0 || ncand[gi - 1] <= 1) {
                 const unsigned int list = (unsigned int)(gi >> 2) & (RUN_LISTS - 1);
                 const unsigned int pos = atomicAdd(run_count + list * RF_CSTRIDE, 1u);
-                runs[(size_t)list * run_cap + pos] = PathRun{gi, sl, 0};
+                runs[(size_t)list * run_cap + pos] = PathRun{gi, slices[sl].frame_off + slices[sl].n_frames, li > 0 ? 1 : 0, 0};
             }
         }
     }
@@ -999,17 +998,24 @@ __global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const PiSlice *
 // Viterbi over one run of multi-candidate frames per wavefront.  Lane ic (0..15) owns
 // candidate ic of the current frame; the previous frame's running delta and log2-frequency
 // stay in those lanes' registers and are broadcast with v_readlane (the loop over previous
-// candidates is wave-uniform), so the recurrence touches neither LDS nor a barrier.
+// candidates is wave-uniform), so the recurrence touches neither a barrier nor global memory.
+// Runs are short (speech: tens of frames, a few hundred at most), so everything around the
+// recurrence is sized for that: operands arrive in 16-frame chunks (one 16-byte load per lane
+// and four frames per instruction, the next chunk in flight while this one is consumed), the
+// back-pointers stay in LDS for runs up to PT_CAP frames, and the workgroup is the wavefront
+// (no __syncthreads).  Longer runs back-track through global memory in tiles.
+constexpr int PT_CHUNK = 16;
+constexpr int PT_CAP = 1024;
 __global__ __launch_bounds__(64) void k_pitch_path(
-    const PiSlice *__restrict__ slices, PiParams P, const double *__restrict__ cand, const int *__restrict__ ncand,
+    PiParams P, const double *__restrict__ cand, const int *__restrict__ ncand,
     const double2 *__restrict__ dl, const PathRun *__restrict__ runs, const unsigned int *__restrict__ run_count, unsigned int run_cap,
     unsigned char *__restrict__ psi /* [frames][16] */, double *__restrict__ f0, double *__restrict__ strength)
 {
-    __shared__ double2 t_dl[PATH_TILE][PI_MAXC];
-    __shared__ int t_n[PATH_TILE];
-    __shared__ __attribute__((aligned(16))) unsigned char t_psi[BT_TILE][PI_MAXC];
-    __shared__ unsigned char t_place[BT_TILE];
-    __shared__ int s_place;
+    __shared__ double2 t_dl[2][PT_CHUNK][PI_MAXC];
+    __shared__ int t_n[2][PT_CHUNK];
+    __shared__ __attribute__((aligned(16))) unsigned char t_psi[PT_CAP][PI_MAXC];
+    __shared__ unsigned char t_place[PT_CAP];
+    static_assert(BT_TILE <= PT_CAP, "the global back-tracking tiles reuse t_psi");
     const int lane = threadIdx.x;
     const int ic = lane & 15;
     const double timeStepCorrection = 0.01 / P.dt;
@@ -1018,30 +1024,43 @@ __global__ __launch_bounds__(64) void k_pitch_path(
     const unsigned int count = run_count[list * RF_CSTRIDE];
     for (unsigned int r = blockIdx.x / RUN_LISTS; r < count; r += gridDim.x / RUN_LISTS) {
         const PathRun run = runs[(size_t)list * run_cap + r];
-        const PiSlice s = slices[run.slice];
-        const long long gs = run.frame, gend = s.frame_off + s.n_frames;     // run start, slice end (global frame indices)
+        const long long gs = run.frame, gend = run.gend;
         double pd = 0.0, plf = PATH_VOICELESS;           // previous frame, candidate `ic`
         int pn = 0;
-        if (gs > s.frame_off) {                          // the cut frame before the run: its only candidate is voiceless
-            pd = dl[(gs - 1) * PI_MAXC].x; plf = PATH_VOICELESS; pn = 1;
-        }
-        long long ge = gs;                               // one past the last frame of the run
+        if (run.has_prev) { pd = dl[(gs - 1) * PI_MAXC].x; pn = 1; }   // the cut frame before the run: one voiceless candidate
+        double2 rg[4]; int rn = 0;                        // chunk in flight
+        auto fetch = [&](long long g0) {
+            const int tn = (int)min((long long)PT_CHUNK, gend - g0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = lane + 64 * q;
+                rg[q] = (e >> 4) < tn ? dl[g0 * PI_MAXC + e] : make_double2(0.0, 0.0);
+            }
+            rn = lane < tn ? ncand[g0 + lane] : 0;        // 0 candidates past the slice end: the run stops there
+        };
+        auto stage = [&](int b) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) (&t_dl[b][0][0])[lane + 64 * q] = rg[q];
+            if (lane < PT_CHUNK) t_n[b][lane] = rn;
+        };
+        wave_sync();                                      // the previous run's LDS readers are done
+        fetch(gs);
+        stage(0);
+        long long ge = gs;                                // one past the last frame of the run
+        int buf = 0;
         bool open = true;
         while (open) {
-            const int tn = (int)min((long long)PATH_TILE, gend - ge);
-            __syncthreads();
-            for (int e = lane; e < tn * PI_MAXC; e += 64) (&t_dl[0][0])[e] = dl[ge * PI_MAXC + e];
-            if (lane < tn) t_n[lane] = ncand[ge + lane];
-            __syncthreads();
+            const bool more = ge + PT_CHUNK < gend;
+            if (more) fetch(ge + PT_CHUNK);
+            wave_sync();
             int fr = 0;
-            double2 cur = t_dl[0][ic];
-            int n2 = t_n[0];
-            unsigned char *pp = psi + ge * PI_MAXC + ic;
-            for (; fr < tn; fr++) {
+            int n2 = t_n[buf][0];
+            double2 cur = t_dl[buf][0][ic];
+            for (; fr < PT_CHUNK; fr++) {
                 if (n2 <= 1) { open = false; break; }
-                const int nx = fr + 1 < tn ? fr + 1 : fr;
-                const double2 nxt = t_dl[nx][ic];             // prefetch the next frame's operands
-                const int n2n = t_n[nx];
+                const int nx = fr + 1 < PT_CHUNK ? fr + 1 : fr;
+                const int n2n = t_n[buf][nx];                 // next frame's operands: off the recurrence's critical path
+                const double2 nxt = t_dl[buf][nx][ic];
                 const double d2 = cur.x, lf2 = cur.y;
                 double best = d2; int place = 0;
                 if (pn > 0) {
@@ -1057,15 +1076,23 @@ __global__ __launch_bounds__(64) void k_pitch_path(
                     }
                 }
                 pd = best; plf = lf2; pn = n2;
-                pp[fr * PI_MAXC] = (unsigned char)place;      // lanes 16..63 rewrite the same bytes
+                const long long idx = ge + fr - gs;
+                if (lane < PI_MAXC) {
+                    psi[(ge + fr) * PI_MAXC + ic] = (unsigned char)place;
+                    if (idx < PT_CAP) t_psi[idx][ic] = (unsigned char)place;
+                }
                 cur = nxt; n2 = n2n;
             }
             ge += fr;
-            if (ge >= gend) open = false;
+            if (open) {
+                if (more) { stage(buf ^ 1); buf ^= 1; }
+                else open = false;
+            }
         }
         // choose the end of the path inside the run
+        int place = 0;
         {
-            int place = 0; double maximum = -1e30;
+            double maximum = -1e30;
             const bool cut_follows = ge < gend;          // frame `ge` is a cut frame (single voiceless candidate)
             const double dn = cut_follows ? dl[ge * PI_MAXC].x : 0.0;
             for (int jc = 0; jc < pn; jc++) {
@@ -1073,31 +1100,47 @@ __global__ __launch_bounds__(64) void k_pitch_path(
                 const double value = cut_follows ? (v - ((lf > 1e299) ? 0.0 : vuc) + dn) : v;
                 if (jc == 0 || value > maximum) { place = jc; maximum = value; }
             }
-            if (lane == 0) s_place = place;
         }
-        __threadfence_block();
-        __syncthreads();
-        // back-track through LDS tiles, last tile first
-        for (long long hi = ge; hi > gs;) {
-            const long long lo = max(gs, hi - BT_TILE);
-            const int cnt = (int)(hi - lo);
-            for (int e = lane; e < cnt; e += 64)
-                *reinterpret_cast<uint4 *>(&t_psi[e][0]) = *reinterpret_cast<const uint4 *>(psi + (lo + e) * PI_MAXC);
-            __syncthreads();
+        const long long L = ge - gs;
+        wave_sync();
+        if (L <= PT_CAP) {
+            // back-track in LDS (one lane walks the chain), then every lane emits frames
             if (lane == 0) {
-                int place = s_place;
-                for (int i = cnt - 1; i >= 0; i--) { t_place[i] = (unsigned char)place; place = t_psi[i][place]; }
-                s_place = place;
+                int pl = place;
+                for (int i = (int)L - 1; i >= 0; i--) { t_place[i] = (unsigned char)pl; pl = t_psi[i][pl]; }
             }
-            __syncthreads();
-            for (int e = lane; e < cnt; e += 64) {
-                const long long gi = lo + e;
+            wave_sync();
+            for (int e = lane; e < (int)L; e += 64) {
+                const long long gi = gs + e;
                 const int pl = t_place[e];
                 f0[gi] = cand[gi * 32 + pl];
                 strength[gi] = cand[gi * 32 + 16 + pl];
             }
-            __syncthreads();
-            hi = lo;
+        } else {
+            // long run: back-track through the global back-pointers in tiles, last tile first
+            __threadfence();
+            for (long long hi = ge; hi > gs;) {
+                const long long lo = max(gs, hi - BT_TILE);
+                const int cnt = (int)(hi - lo);
+                for (int e = lane; e < cnt; e += 64)
+                    *reinterpret_cast<uint4 *>(&t_psi[e][0]) = *reinterpret_cast<const uint4 *>(psi + (lo + e) * PI_MAXC);
+                wave_sync();
+                if (lane == 0) {
+                    int pl = place;
+                    for (int i = cnt - 1; i >= 0; i--) { t_place[i] = (unsigned char)pl; pl = t_psi[i][pl]; }
+                    place = pl;
+                }
+                place = __shfl(place, 0, 64);
+                wave_sync();
+                for (int e = lane; e < cnt; e += 64) {
+                    const long long gi = lo + e;
+                    const int pl = t_place[e];
+                    f0[gi] = cand[gi * 32 + pl];
+                    strength[gi] = cand[gi * 32 + 16 + pl];
+                }
+                wave_sync();
+                hi = lo;
+            }
         }
     }
 }
@@ -1415,7 +1458,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             {
                 KernelTimer t(c, PCE_K_PITCH_PATH);
                 const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 16u;     // multiple of RUN_LISTS
-                hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, c->stream, c->pi_meta.as<PiSlice>(), P,
+                hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, c->stream, P,
                                    c->pi_cand.as<double>(), ncand, c->pi_dl.as<double2>(), runs, run_count, run_cap,
                                    c->pi_psi.as<unsigned char>(), c->pi_f0.as<double>(), c->pi_strength.as<double>());
             }
