@@ -732,14 +732,24 @@ __device__ __forceinline__ double sinc_w(double kd, double a0, double yu /* y (1
 {
     return yu * rcp_f64(fma(kd, PI_D, a0));         // the side's +-0.5 sin factor is applied once per side
 }
-__device__ __forceinline__ double sinc_group_reg(const double (&yv)[18], int wbase, int ynx, double x, int maxDepth, int l8)
+template <int G> __device__ __forceinline__ double group_sum(double v)
 {
+    v += dpp_f64<0xB1>(v);                              // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);                              // quad_perm [2,3,0,1]
+    if (G == 8) v += dpp_f64<0x141>(v);                 // row_half_mirror
+    return v;
+}
+// G lanes per candidate, NR = 144 / G rows per lane; row RS straddles x, rows < RS lie left, rows > RS right.
+template <int G>
+__device__ __forceinline__ double sinc_group_reg(const double (&yv)[144 / G], int wbase, int ynx, double x, int maxDepth, int lg)
+{
+    constexpr int NR = 144 / G, RS = (72 - G) / G;
     const int midleft = (int)floor(x), midright = midleft + 1;
     if (x == (double)midleft) {
         double pick = 0.0;
 #pragma unroll
-        for (int m = 0; m < 18; m++) if (wbase + l8 + 8 * m == midleft) pick = yv[m];
-        return row_sum8(pick);
+        for (int m = 0; m < NR; m++) if (wbase + lg + G * m == midleft) pick = yv[m];
+        return group_sum<G>(pick);
     }
     int D = maxDepth;
     if (D > midright - 1) D = midright - 1;
@@ -751,57 +761,59 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[18], int wba
     const double rden_l = rcp_f64(x - (double)left + 1.0), rden_r = rcp_f64((double)right - x + 1.0);
     const double aa_l = a_l * rden_l, daa_l = PI_D * rden_l;
     const double aa_r = a_r * rden_r, daa_r = PI_D * rden_r;
-    const int kl0 = midleft - wbase - l8;             // k of row 0 on the left side (decreases by 8 per row)
-    const int kr0 = wbase + l8 - midright;            // k of row 0 on the right side (increases by 8 per row)
+    const int kl0 = midleft - wbase - lg;             // k of row 0 on the left side (decreases by G per row)
+    const int kr0 = wbase + lg - midright;            // k of row 0 on the right side (increases by G per row)
     const double hs_l = (kl0 & 1) ? -hs : hs, hs_r = (kr0 & 1) ? -hs : hs;
     const double kdl = (double)kl0, kdr = (double)kr0;
-    // rows 0..7 and 9..17 have k >= 0 by construction (wbase = ixmid - 71): only the depth limit can drop them
+    // rows < RS and > RS have k >= 0 by construction (wbase = ixmid - 71): only the depth limit can drop them
     auto keep = [&](double kd, double t) { return kd < dlim ? t : 0.0; };
     double acc;
-    {   // row 8 holds the lanes around x
-        const bool is_left = kl0 - 64 >= 0;
-        const double kd = is_left ? kdl - 64.0 : kdr + 64.0;
+    {   // row RS holds the lanes around x
+        const bool is_left = kl0 - G * RS >= 0;
+        const double kd = is_left ? kdl - (double)(G * RS) : kdr + (double)(G * RS);
         const double u = one_plus_cos_0pi(fma(kd, is_left ? daa_l : daa_r, is_left ? aa_l : aa_r));
-        const double t8 = (is_left ? hs_l : hs_r) * sinc_w(kd, is_left ? a_l : a_r, yv[8] * u);
-        acc = (kd >= 0.0 && kd < dlim) ? t8 : 0.0;
+        const double ts = (is_left ? hs_l : hs_r) * sinc_w(kd, is_left ? a_l : a_r, yv[RS] * u);
+        acc = (kd >= 0.0 && kd < dlim) ? ts : 0.0;
     }
-    {   // left side, rows 7 (nearest x) .. 0
-        const double cq = cos_q(4.0 * daa_l);                           // cos(delta / 2), delta = 8 daa <= pi
+    {   // left side, rows RS-1 (nearest x) .. 0
+        const double cq = cos_q(0.5 * G * daa_l);                       // cos(delta / 2), delta = G daa <= pi
         const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
-        double u1 = one_plus_cos_0pi(fma(kdl - 56.0, daa_l, aa_l));     // row 7
-        double u0 = one_plus_cos_0pi(fma(kdl - 48.0, daa_l, aa_l));     // row 6
-        double side = keep(kdl - 56.0, sinc_w(kdl - 56.0, a_l, yv[7] * u1));
-        side += keep(kdl - 48.0, sinc_w(kdl - 48.0, a_l, yv[6] * u0));
+        const double k1 = kdl - (double)(G * (RS - 1)), k0 = kdl - (double)(G * (RS - 2));
+        double u1 = one_plus_cos_0pi(fma(k1, daa_l, aa_l));
+        double u0 = one_plus_cos_0pi(fma(k0, daa_l, aa_l));
+        double side = keep(k1, sinc_w(k1, a_l, yv[RS - 1] * u1));
+        side += keep(k0, sinc_w(k0, a_l, yv[RS - 2] * u0));
 #pragma unroll
-        for (int m = 5; m >= 0; m--) {
+        for (int m = RS - 3; m >= 0; m--) {
             const double u = fma(tc, u0, g - u1);        // (g - u1) is off the critical path
             u1 = u0; u0 = u;
-            const double kd = kdl - 8.0 * m;
+            const double kd = kdl - (double)(G * m);
             side += keep(kd, sinc_w(kd, a_l, yv[m] * u));
         }
         acc = fma(hs_l, side, acc);
     }
-    {   // right side, rows 9 (nearest x) .. 17
-        const double cq = cos_q(4.0 * daa_r);
+    {   // right side, rows RS+1 (nearest x) .. NR-1
+        const double cq = cos_q(0.5 * G * daa_r);
         const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
-        double u1 = one_plus_cos_0pi(fma(kdr + 72.0, daa_r, aa_r));     // row 9
-        double u0 = one_plus_cos_0pi(fma(kdr + 80.0, daa_r, aa_r));     // row 10
-        double side = keep(kdr + 72.0, sinc_w(kdr + 72.0, a_r, yv[9] * u1));
-        side += keep(kdr + 80.0, sinc_w(kdr + 80.0, a_r, yv[10] * u0));
+        const double k1 = kdr + (double)(G * (RS + 1)), k0 = kdr + (double)(G * (RS + 2));
+        double u1 = one_plus_cos_0pi(fma(k1, daa_r, aa_r));
+        double u0 = one_plus_cos_0pi(fma(k0, daa_r, aa_r));
+        double side = keep(k1, sinc_w(k1, a_r, yv[RS + 1] * u1));
+        side += keep(k0, sinc_w(k0, a_r, yv[RS + 2] * u0));
 #pragma unroll
-        for (int m = 11; m < 18; m++) {
+        for (int m = RS + 3; m < NR; m++) {
             const double u = fma(tc, u0, g - u1);        // (g - u1) is off the critical path
             u1 = u0; u0 = u;
-            const double kd = kdr + 8.0 * m;
+            const double kd = kdr + (double)(G * m);
             side += keep(kd, sinc_w(kd, a_r, yv[m] * u));
         }
         acc = fma(hs_r, side, acc);
     }
-    return row_sum8(acc);
+    return group_sum<G>(acc);
 }
 
 // generic NUM_interpolate_sinc with y in global memory (depth 700, or windows near the array ends)
-__device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x, int maxDepth, int l8)
+template <int G> __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x, int maxDepth, int lg)
 {
     const int midleft = (int)floor(x), midright = midleft + 1;
     if (x > (double)ynx) return y[ynx - 1];
@@ -824,7 +836,7 @@ __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x
     const double aa_l = a_l / den_l, daa_l = PI_D / den_l;
     const double aa_r = a_r / den_r, daa_r = PI_D / den_r;
     double acc = 0.0;
-    for (int t = l8; t < 2 * maxDepth; t += 8) {
+    for (int t = lg; t < 2 * maxDepth; t += G) {
         const bool is_left = t < maxDepth;
         const int k = is_left ? t : t - maxDepth;
         const double kd = (double)k;
@@ -835,18 +847,20 @@ __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x
         const int ix = is_left ? midleft - k : midright + k;
         acc += y[ix - 1] * (hs * rcp_f64(a) * one_plus_cos_0pi(aa));
     }
-    return row_sum8(acc);
+    return group_sum<G>(acc);
 }
 
-__global__ __launch_bounds__(256, 3) void k_pitch_refine(PiParams P, const double *__restrict__ rr_in, const RefineItem *__restrict__ items,
+template <int G>
+__global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P, const double *__restrict__ rr_in, const RefineItem *__restrict__ items,
                                                      const unsigned int *__restrict__ item_count, unsigned int list_cap,
                                                      double *__restrict__ cand)
 {
-    const int l8 = threadIdx.x & 7;
-    const unsigned int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    constexpr int NR = 144 / G, GS = G == 8 ? 3 : 2;
+    const int l8 = threadIdx.x & (G - 1);
+    const unsigned int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> GS;
     const unsigned int list = gid & (RF_LISTS - 1);
     const unsigned int group = gid / RF_LISTS;
-    const unsigned int n_groups = ((gridDim.x * blockDim.x) >> 3) / RF_LISTS;
+    const unsigned int n_groups = ((gridDim.x * blockDim.x) >> GS) / RF_LISTS;
     const unsigned int count = item_count[list * RF_CSTRIDE];
     items += (size_t)list * list_cap;
     const int ynx = 2 * P.bix + 1;
@@ -871,7 +885,7 @@ __global__ __launch_bounds__(256, 3) void k_pitch_refine(PiParams P, const doubl
     const double *y = rr_in;
     int wbase = 0, depth = 70, iter = 0;
     bool fast = false;
-    double yv[18];
+    double yv[NR];
     double a = 0.0, b = 0.0, v = 0.0, w = 0.0, x = 0.0, fv = 0.0, fw = 0.0, fx = 0.0, t = 0.0;
     for (;;) {
         while (!have && it < count) {
@@ -890,8 +904,8 @@ __global__ __launch_bounds__(256, 3) void k_pitch_refine(PiParams P, const doubl
             fast = depth == 70 && ixmid - 1 >= 9 && ynx - ixmid >= 8;
             wbase = ixmid - 71;
 #pragma unroll
-            for (int m = 0; m < 18; m++) {
-                const int ix = wbase + l8 + 8 * m;
+            for (int m = 0; m < NR; m++) {
+                const int ix = wbase + l8 + G * m;
                 yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[ix - 1] : 0.0;
             }
             a = (double)(ixmid - 1); b = (double)(ixmid + 1);
@@ -900,7 +914,7 @@ __global__ __launch_bounds__(256, 3) void k_pitch_refine(PiParams P, const doubl
         }
         if (__ballot(have) == 0) break;
         if (have) {
-            const double ft = fast ? -sinc_group_reg(yv, wbase, ynx, t, 70, l8) : -sinc_group_mem(y, ynx, t, depth, l8);
+            const double ft = fast ? -sinc_group_reg<G>(yv, wbase, ynx, t, 70, l8) : -sinc_group_mem<G>(y, ynx, t, depth, l8);
             if (iter == 0) {
                 x = v; w = v; fx = ft; fw = ft; fv = ft;
             } else if (ft <= fx) {
@@ -1438,8 +1452,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                 KernelTimer t(c, PCE_K_PITCH_REFINE);
                 // 3 workgroups per CU are resident (168 VGPRs); 24 per CU measured best (1.30 ms against 1.47 at 3: the lists are uneven)
                 const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (getenv("PCE_K2_BPC") ? (unsigned)atoi(getenv("PCE_K2_BPC")) : 24u);
-                hipLaunchKernelGGL(k_pitch_refine, dim3(blocks), dim3(256), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
-                                   list_cap, c->pi_cand.as<double>());
+                hipLaunchKernelGGL(k_pitch_refine<8>, dim3(blocks), dim3(256), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
+                                   list_cap, c->pi_cand.as<double>());   // (4 lanes per candidate measured slower: 1.66 against 1.35 ms)
             }
         }
         {
