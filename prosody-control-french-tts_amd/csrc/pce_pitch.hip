@@ -82,7 +82,7 @@ constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte line
 struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
     int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, mode, fpb;
-    int o_tw2, o_twN, o_win, o_winR, blob_f64, pcm_span, tabs, pad3;   // register paths: table blob layout (offsets in doubles)
+    int o_tw2, o_twN, o_win, o_winR, blob_f64, pcm_span, tabs, rr_half;   // register paths: table blob layout (offsets in doubles)
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const double2 *__restrict__ twM /* exp(-2 pi i m / M), m < M */, const double2 *__restrict__ twN /* exp(-2 pi i k / N), k <= M */,
     const long long *acc_sum, const int *acc_hi, const int *acc_lo, size_t acc_stride,
     double *__restrict__ cand /* [frames][32]: 16 freq, 16 strength */, int *__restrict__ ncand, double *__restrict__ intensity,
-    double *__restrict__ rr_out /* [frames][rr_len] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
+    double *__restrict__ rr_out /* [frames][rr_half]: r[0..bix] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
     unsigned int list_cap, int dbg, const double *__restrict__ blob /* register paths: lane-ordered twiddles, twN, window, windowR */)
 {
     constexpr int LW = MODE == 2 ? 32 : 64;              // lanes per frame
@@ -633,8 +633,9 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
         }
         if (n > 1 && !(dbg & 2)) {
             // hand r[-bix..bix] and the candidate lags to k_pitch_refine
-            double *ro = rr_out + fidx * (int64_t)P.rr_len;
-            for (int k = hl; k < ynx; k += LW) ro[k] = rr[k];
+            // r is even: only r[0..bix] travels (half the bytes written here and read by k_pitch_refine)
+            double *ro = rr_out + fidx * (int64_t)P.rr_half;
+            for (int k = hl; k <= P.bix; k += LW) ro[k] = rr[P.bix + k];
             // append to one of RF_LISTS lists: a single counter would serialise ~10^5 returning atomics in L2
             const unsigned int list = (unsigned int)bid & (RF_LISTS - 1);
             unsigned int pos = 0;
@@ -643,10 +644,8 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
             if (hl >= 1 && hl < n) items[(size_t)list * list_cap + pos + hl - 1] = RefineItem{(long long)fidx, hl, c_i};
         }
     }
-    if (live && hl < PI_MAXC) {
-        cand[fidx * 32 + hl] = 0.0;
-        cand[fidx * 32 + 16 + hl] = 0.0;
-    }
+    // (candidate slots are not cleared: slot 0 is the voiceless candidate by definition and slots >= n are
+    //  never read -- k_pitch_delta and k_pitch_path go by ncand)
     if (live && hl == 0) { ncand[fidx] = n; intensity[fidx] = inten; }
     }   // frames of this wavefront
 }
@@ -813,19 +812,21 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[144 / G], in
 }
 
 // generic NUM_interpolate_sinc with y in global memory (depth 700, or windows near the array ends)
-template <int G> __device__ double sinc_group_mem(const double *__restrict__ y, int ynx, double x, int maxDepth, int lg)
+template <int G> __device__ double sinc_group_mem(const double *__restrict__ yh /* r[0..bix] */, int ynx, double x, int maxDepth, int lg)
 {
+    const int mid = (ynx + 1) >> 1;                      // Praat's y(i) = r[i - mid] = yh[|i - mid|]
+    auto Y = [&](int i) { return yh[abs(i - mid)]; };
     const int midleft = (int)floor(x), midright = midleft + 1;
-    if (x > (double)ynx) return y[ynx - 1];
-    if (x < 1.0) return y[0];
-    if (x == (double)midleft) return y[midleft - 1];
+    if (x > (double)ynx) return Y(ynx);
+    if (x < 1.0) return Y(1);
+    if (x == (double)midleft) return Y(midleft);
     if (maxDepth > midright - 1) maxDepth = midright - 1;
     if (maxDepth > ynx - midleft) maxDepth = ynx - midleft;
-    if (maxDepth <= 0) return y[(int)floor(x + 0.5) - 1];
-    if (maxDepth == 1) return y[midleft - 1] + (x - (double)midleft) * (y[midright - 1] - y[midleft - 1]);
+    if (maxDepth <= 0) return Y((int)floor(x + 0.5));
+    if (maxDepth == 1) return Y(midleft) + (x - (double)midleft) * (Y(midright) - Y(midleft));
     if (maxDepth == 2) {
-        const double yl = y[midleft - 1], yr = y[midright - 1];
-        const double dyl = 0.5 * (yr - y[midleft - 2]), dyr = 0.5 * (y[midright] - yl);
+        const double yl = Y(midleft), yr = Y(midright);
+        const double dyl = 0.5 * (yr - Y(midleft - 1)), dyr = 0.5 * (Y(midright + 1) - yl);
         const double fil = x - (double)midleft, fir = (double)midright - x;
         return yl * fir + yr * fil - fil * fir * (0.5 * (dyr - dyl) + (fil - 0.5) * (dyl + dyr - 2.0 * (yr - yl)));
     }
@@ -845,7 +846,7 @@ template <int G> __device__ double sinc_group_mem(const double *__restrict__ y, 
         double hs = is_left ? hs_l : hs_r;
         if (k & 1) hs = -hs;
         const int ix = is_left ? midleft - k : midright + k;
-        acc += y[ix - 1] * (hs * rcp_f64(a) * one_plus_cos_0pi(aa));
+        acc += Y(ix) * (hs * rcp_f64(a) * one_plus_cos_0pi(aa));
     }
     return group_sum<G>(acc);
 }
@@ -891,12 +892,12 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
         while (!have && it < count) {
             item = items[it];
             it += n_groups;
-            y = rr_in + item.frame * (long long)P.rr_len;                // y[i-1] = Praat's y[i]
+            y = rr_in + item.frame * (long long)P.rr_half;               // Praat's y(i) = r[i - mid] = y[|i - mid|], mid = bix + 1
             const int ixmid = item.imax + P.bix + 1;
-            if (ixmid <= 1) { finish(item, 1.0, y[0]); continue; }
-            if (ixmid >= ynx) { finish(item, (double)ynx, y[ynx - 1]); continue; }
+            if (ixmid <= 1) { finish(item, 1.0, y[P.bix]); continue; }
+            if (ixmid >= ynx) { finish(item, (double)ynx, y[P.bix]); continue; }
             // depth choice uses the first-pass (parabolic) frequency, as Praat does
-            const double r0 = y[ixmid - 1], rm = y[ixmid - 2], rp = y[ixmid];
+            const double r0 = y[abs(item.imax)], rm = y[abs(item.imax - 1)], rp = y[abs(item.imax + 1)];
             const double dr = 0.5 * (rp - rm), d2r = 2.0 * r0 - rm - rp;
             const double f1 = 1.0 / P.dx / ((double)item.imax + dr / d2r);
             depth = f1 > 0.3 / P.dx ? 700 : 70;
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
 #pragma unroll
             for (int m = 0; m < NR; m++) {
                 const int ix = wbase + l8 + G * m;
-                yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[ix - 1] : 0.0;
+                yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[abs(ix - P.bix - 1)] : 0.0;
             }
             a = (double)(ixmid - 1); b = (double)(ixmid + 1);
             v = a + golden * (b - a);
@@ -986,16 +987,18 @@ __global__ __launch_bounds__(256) void k_pitch_delta(PiParams P, const PiSlice *
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_frames * PI_MAXC) return;
     const long long gi = e >> 4; const int jc = (int)(e & 15);
-    const double f = cand[gi * 32 + jc], st = cand[gi * 32 + 16 + jc];
+    const int n_here = ncand[gi];
+    const bool real = jc >= 1 && jc < n_here;             // slot 0 is the voiceless candidate; slots >= n do not exist
+    const double f = real ? cand[gi * 32 + jc] : 0.0, st = real ? cand[gi * 32 + 16 + jc] : 0.0;
     const double inten = intensity[gi];
     double uv = P.silence_thr <= 0.0 ? 0.0 : 2.0 - inten / (P.silence_thr / (1.0 + P.voicing_thr));
     uv = P.voicing_thr + (uv > 0.0 ? uv : 0.0);
     const bool voiceless_local = f == 0.0 || f > P.ceiling;
     const bool voiceless_trans = f <= 0.0 || f >= P.ceiling;
     const double delta = voiceless_local ? uv : st - P.octave_cost * (log(P.ceiling / f) * LOG2E_D);
-    dl[e] = make_double2(delta, voiceless_trans ? PATH_VOICELESS : log(f) * LOG2E_D);
+    if (jc < max(n_here, 1)) dl[e] = make_double2(delta, voiceless_trans ? PATH_VOICELESS : log(f) * LOG2E_D);
     if (jc == 0) {
-        const int n = ncand[gi];
+        const int n = n_here;
         if (n <= 1) { f0[gi] = 0.0; strength[gi] = 0.0; }
         else {
             const int sl = frame_slice[gi];
@@ -1127,8 +1130,8 @@ __global__ __launch_bounds__(64) void k_pitch_path(
             for (int e = lane; e < (int)L; e += 64) {
                 const long long gi = gs + e;
                 const int pl = t_place[e];
-                f0[gi] = cand[gi * 32 + pl];
-                strength[gi] = cand[gi * 32 + 16 + pl];
+                f0[gi] = pl ? cand[gi * 32 + pl] : 0.0;
+                strength[gi] = pl ? cand[gi * 32 + 16 + pl] : 0.0;
             }
         } else {
             // long run: back-track through the global back-pointers in tiles, last tile first
@@ -1149,8 +1152,8 @@ __global__ __launch_bounds__(64) void k_pitch_path(
                 for (int e = lane; e < cnt; e += 64) {
                     const long long gi = lo + e;
                     const int pl = t_place[e];
-                    f0[gi] = cand[gi * 32 + pl];
-                    strength[gi] = cand[gi * 32 + 16 + pl];
+                    f0[gi] = pl ? cand[gi * 32 + pl] : 0.0;
+                    strength[gi] = pl ? cand[gi * 32 + 16 + pl] : 0.0;
                 }
                 wave_sync();
                 hi = lo;
@@ -1308,6 +1311,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             const int Mc = nfft / 2;
             P.zlen = Mc + Mc / 8 + 2;
             P.rr_len = 2 * P.bix + 2;
+            P.rr_half = (P.bix + 2) & ~1;                  // handoff row: r[0..bix], even length
             const size_t lds_wave = sizeof(double) * 4 * (size_t)P.zlen;            // two complex buffers per wavefront
             if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
             // register-resident transforms where N allows it and r[-bix..bix] fits the exchange region
@@ -1384,7 +1388,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         PCE_HIP(c, c->pi_runs.reserve(sizeof(unsigned int) * RUN_LISTS * RF_CSTRIDE + sizeof(PathRun) * (size_t)RUN_LISTS * (size_t)(total / RUN_LISTS + 64)));
         PCE_HIP(c, c->pi_fslice.reserve(sizeof(int) * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_dl.reserve(sizeof(double) * 2 * PI_MAXC * (size_t)(total + 1)));
-        PCE_HIP(c, c->pi_rr.reserve(sizeof(double) * (size_t)P.rr_len * (size_t)(total + 1)));
+        PCE_HIP(c, c->pi_rr.reserve(sizeof(double) * (size_t)P.rr_half * (size_t)(total + 1)));
         PCE_HIP(c, c->pi_items.reserve(sizeof(RefineItem) * (size_t)(PI_MAXC - 1) * (size_t)(2 * PI_FPB) * (size_t)(div_up((int64_t)work.size() + 8, RF_LISTS) * RF_LISTS + RF_LISTS)
                                        + sizeof(unsigned int) * RF_LISTS * RF_CSTRIDE));
         PCE_HIP(c, hipMemcpyAsync(c->pi_meta.p, hs.data(), sizeof(PiSlice) * hs.size(), hipMemcpyHostToDevice, c->stream));
