@@ -107,7 +107,11 @@ def main():
         wdims = WW.DIMS["small"]
         eng.whisper_load(wdims, WW.pack(WW.synthetic_weights(wdims), wdims))       # random-init weights of the architecture
 
-    def step():
+    # One step = one pass of the hot path over the batch: launch() enqueues every kernel of the pass and the
+    # asynchronous copy of the per-utterance statistics; finish() waits for that copy only, builds the 7-stat
+    # record and all-gathers it.  Consecutive steps are software-pipelined (step i+1 is enqueued before step i's
+    # record is read), so the device does not idle while the host unpacks: two statistic slots are in flight.
+    def launch(slot):
         if wdims:
             eng.logmel_run(wdims["n_mels"])
             eng.whisper_encode_run()
@@ -115,13 +119,25 @@ def main():
         eng.lufs_run(sl)
         eng.pitch_run(sl, params)
         eng.stft_db_run(1024, 256)
-        en = eng.energy_fetch()
-        lu, _ = eng.lufs_fetch()
-        pi = eng.pitch_fetch(want_f0=False)["summary"]
+        eng.stats_enqueue(slot)
+
+    def finish(slot):
+        r = eng.stats_wait(slot)
+        en, lu, pi = r["energy"], r["lufs"][0], r["pitch"]
         # per-utterance record: [median F0, LUFS, rms, peak, silence ratio, duration, n_voiced]
         rec = np.stack([pi["median_f0"], lu, np.sqrt(en["sum_sq"] / np.maximum(en["n"], 1)), en["peak_abs"].astype(np.float64),
                         1.0 - en["n_loud"] / np.maximum(en["n"], 1), en["n"] / float(rate), pi["n_voiced"].astype(np.float64)], axis=1)
         return shard.allgather_records(rec)
+
+    def run_steps(k):
+        rec = None
+        for i in range(k):
+            launch(i & 1)
+            if i > 0:
+                rec = finish((i - 1) & 1)
+        if k > 0:
+            rec = finish((k - 1) & 1)
+        return rec
 
     def fence():
         if world > 1:
@@ -129,15 +145,13 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     if not args.no_profile:
         eng.profile_enable(True)
         eng.profile_reset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec = step()
+    rec = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     prof = eng.profile() if not args.no_profile else {}

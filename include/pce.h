@@ -227,6 +227,16 @@ int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32
 int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32_t batch, int32_t *path_i, int32_t *path_j,
             int32_t *path_len);
 
+/* ---- asynchronous statistics fetch ---------------------------------------
+ * The per-slice numbers of the last pce_energy_run / pce_lufs_run / pce_pitch_run are what the reference's
+ * driver consumes per utterance (Code/audioPipeline.py:380-400) and what the sharded driver all-gathers
+ * (SURVEY.md 8e).  pce_stats_enqueue queues their device-to-host copies behind those runs into pinned
+ * staging memory and returns at once; pce_stats_wait blocks only on those copies and unpacks them, so the
+ * next batch's kernels can already be running.  slot is 0 or 1 (two batches in flight).  Any output pointer
+ * may be NULL; a non-NULL pointer whose run did not precede the enqueue is an error (PCE_E_STATE). */
+int pce_stats_enqueue(pce_ctx *ctx, int32_t slot);
+int pce_stats_wait(pce_ctx *ctx, int32_t slot, pce_energy *energy, double *lufs, int32_t *lufs_status, pce_pitch_summary *pitch);
+
 /* ---- measurement -------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; pce_profile_get returns the accumulated device time. */

@@ -1,5 +1,6 @@
 // pce_ctx.hip -- context, batch residency, profiling brackets of libpce.so.
 #include "pce_internal.h"
+#include <cstring>
 #include <cstdarg>
 
 int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...)
@@ -30,9 +31,11 @@ KernelTimer::~KernelTimer()
     (void)hipEventRecord(b, c->stream);
     c->pending.push_back({id, a, b});
 }
-void pce_profile_collect(pce_ctx *ctx)
+void pce_profile_collect(pce_ctx *ctx, bool wait)
 {
+    size_t kept = 0;
     for (auto &p : ctx->pending) {
+        if (!wait && hipEventQuery(p.b) != hipSuccess) { ctx->pending[kept++] = p; continue; }   // still running
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ctx->prof_ms[p.id] += ms;
@@ -41,7 +44,7 @@ void pce_profile_collect(pce_ctx *ctx)
         ctx->ev_pool.push_back(p.a);
         ctx->ev_pool.push_back(p.b);
     }
-    ctx->pending.clear();
+    ctx->pending.resize(kept);
 }
 
 extern "C" {
@@ -93,6 +96,10 @@ void pce_destroy(pce_ctx *c)
                       &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc, &c->pi_rr, &c->pi_items, &c->pi_tw, &c->pi_dl, &c->pi_runs, &c->pi_fslice, &c->pi_blob,
                       &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work};
     for (auto b : bufs) b->release();
+    for (auto &st : c->stat) {
+        if (st.host) (void)hipHostFree(st.host);
+        if (st.ev) (void)hipEventDestroy(st.ev);
+    }
     pce_whisper_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -105,6 +112,62 @@ int pce_sync(pce_ctx *c)
     if (!c) return PCE_E_INVALID;
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
+    return PCE_OK;
+}
+
+int pce_stats_enqueue(pce_ctx *c, int32_t slot)
+{
+    if (!c || slot < 0 || slot > 1) return PCE_E_INVALID;
+    PCE_HIP(c, hipSetDevice(c->device));
+    pce_ctx::StatSlot &st = c->stat[slot];
+    const size_t b_en = pce_energy_stage_bytes(c), b_lu = c->lu_n > 0 ? sizeof(double) * (size_t)c->lu_n : 0, b_pi = pce_pitch_stage_bytes(c);
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t need = up(b_en) + up(b_lu) + up(b_pi) + 64;
+    if (need > st.cap) {
+        if (st.host) { PCE_HIP(c, hipHostFree(st.host)); st.host = nullptr; st.cap = 0; }
+        PCE_HIP(c, hipHostMalloc(&st.host, need + (need >> 2), hipHostMallocDefault));
+        st.cap = need + (need >> 2);
+    }
+    if (!st.ev) PCE_HIP(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    char *base = static_cast<char *>(st.host);
+    st.off_lu = up(b_en); st.off_pi = st.off_lu + up(b_lu);
+    st.en_n = c->en_n; st.lu_n = c->lu_n; st.pi_n = c->pi_n;
+    if (c->en_n >= 0) { int rc = pce_energy_stage_enqueue(c, base, st.en_len); if (rc) return rc; }
+    if (c->lu_n > 0) PCE_HIP(c, hipMemcpyAsync(base + st.off_lu, c->lu_out.p, b_lu, hipMemcpyDeviceToHost, c->stream));
+    if (c->lu_n >= 0) st.lu_status = c->lu_host_status;
+    if (c->pi_n >= 0) {
+        int rc = pce_pitch_stage_enqueue(c, base + st.off_pi); if (rc) return rc;
+        st.pi_frames.resize((size_t)c->pi_n);
+        for (int32_t i = 0; i < c->pi_n; i++) st.pi_frames[(size_t)i] = c->pi_frame_off[(size_t)i + 1] - c->pi_frame_off[(size_t)i];
+        st.pi_t1 = c->pi_t1; st.pi_status = c->pi_status;
+    }
+    PCE_HIP(c, hipEventRecord(st.ev, c->stream));
+    st.armed = true;
+    return PCE_OK;
+}
+
+int pce_stats_wait(pce_ctx *c, int32_t slot, pce_energy *energy, double *lufs, int32_t *lufs_status, pce_pitch_summary *pitch)
+{
+    if (!c || slot < 0 || slot > 1) return PCE_E_INVALID;
+    pce_ctx::StatSlot &st = c->stat[slot];
+    if (!st.armed) return pce_fail(c, PCE_E_STATE, "pce_stats_wait: slot %d has no enqueued fetch", slot);
+    if ((energy && st.en_n < 0) || ((lufs || lufs_status) && st.lu_n < 0) || (pitch && st.pi_n < 0))
+        return pce_fail(c, PCE_E_STATE, "pce_stats_wait: a requested statistic was not computed before pce_stats_enqueue");
+    PCE_HIP(c, hipSetDevice(c->device));
+    PCE_HIP(c, hipEventSynchronize(st.ev));
+    st.armed = false;
+    pce_profile_collect(c, false);
+    const char *base = static_cast<const char *>(st.host);
+    if (energy) pce_energy_stage_unpack(base, st.en_len, energy);
+    if (lufs && st.lu_n > 0) memcpy(lufs, base + st.off_lu, sizeof(double) * (size_t)st.lu_n);
+    if (lufs_status) for (int32_t i = 0; i < st.lu_n; i++) lufs_status[i] = st.lu_status[(size_t)i];
+    if (pitch) {
+        pce_pitch_stage_unpack(base + st.off_pi, st.pi_n, pitch);
+        for (int32_t i = 0; i < st.pi_n; i++) {
+            pitch[i].n_frames = st.pi_frames[(size_t)i]; pitch[i].t1 = st.pi_t1[(size_t)i]; pitch[i].status = st.pi_status[(size_t)i];
+            pitch[i].reserved = 0;
+        }
+    }
     return PCE_OK;
 }
 

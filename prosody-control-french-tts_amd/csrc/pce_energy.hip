@@ -209,3 +209,25 @@ int pce_energy_fetch(pce_ctx *c, pce_energy *out)
 }
 
 } // extern "C"
+
+size_t pce_energy_stage_bytes(const pce_ctx *c) { return c->en_n > 0 ? sizeof(EnAcc) * (size_t)c->en_n : 0; }
+int pce_energy_stage_enqueue(pce_ctx *c, void *pinned, std::vector<int64_t> &lens)
+{
+    lens.resize((size_t)(c->en_n > 0 ? c->en_n : 0));
+    for (int32_t i = 0; i < c->en_n; i++) lens[(size_t)i] = c->en_cache.v[(size_t)i].end - c->en_cache.v[(size_t)i].begin;
+    if (c->en_n > 0)
+        PCE_HIP(c, hipMemcpyAsync(pinned, c->en_out.p, sizeof(EnAcc) * (size_t)c->en_n, hipMemcpyDeviceToHost, c->stream));
+    return PCE_OK;
+}
+void pce_energy_stage_unpack(const void *pinned, const std::vector<int64_t> &lens, pce_energy *out)
+{
+    const EnAcc *acc = static_cast<const EnAcc *>(pinned);
+    for (size_t i = 0; i < lens.size(); i++) {
+        out[i].n = lens[i];
+        out[i].sum_sq = (int64_t)acc[i].sum_sq;
+        out[i].sum_sq_wrap16 = (int64_t)acc[i].sum_wrap;
+        out[i].n_loud = (int64_t)acc[i].n_loud;
+        out[i].peak_abs = acc[i].peak;
+        out[i].reserved = 0;
+    }
+}

@@ -91,6 +91,16 @@ struct pce_ctx {
     // whisper (opaque: defined in pce_whisper.hip)
     void *whisper = nullptr;
 
+    // asynchronous statistics fetch (pce_stats_enqueue / pce_stats_wait)
+    struct StatSlot {
+        void *host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool armed = false;
+        int32_t en_n = -1, lu_n = -1, pi_n = -1;
+        size_t off_lu = 0, off_pi = 0;
+        std::vector<int64_t> en_len, pi_frames;
+        std::vector<int32_t> lu_status, pi_status;
+        std::vector<double> pi_t1;
+    } stat[2];
+
     // profiling
     bool prof = false;
     double prof_ms[PCE_K_COUNT] = {0};
@@ -114,7 +124,15 @@ struct KernelTimer {
     KernelTimer(pce_ctx *ctx, int kid);
     ~KernelTimer();
 };
-void pce_profile_collect(pce_ctx *ctx);
+void pce_profile_collect(pce_ctx *ctx, bool wait = true);   // wait = false: only the launches that have completed
+
+// staged fetch helpers of the modules (pce_stats_*): bytes needed, enqueue the copy into pinned memory, unpack it
+size_t pce_energy_stage_bytes(const pce_ctx *c);
+int pce_energy_stage_enqueue(pce_ctx *c, void *pinned, std::vector<int64_t> &lens);
+void pce_energy_stage_unpack(const void *pinned, const std::vector<int64_t> &lens, pce_energy *out);
+size_t pce_pitch_stage_bytes(const pce_ctx *c);
+int pce_pitch_stage_enqueue(pce_ctx *c, void *pinned);
+void pce_pitch_stage_unpack(const void *pinned, int32_t n, pce_pitch_summary *out);
 
 // Host-side copy of the sizes Praat derives before its frame loop (see pce_pitch.hip).
 struct PitchPlan {

@@ -92,6 +92,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_resample_run", "pce_download_pcm_s16",
            "pce_dtw", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch",
            "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
+           "pce_stats_enqueue", "pce_stats_wait",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
 
@@ -117,6 +118,8 @@ def load_library() -> C.CDLL:
     lib.pce_pitch_plan.argtypes = [vp, C.POINTER(PitchParams), vp, i32, vp, vp]
     lib.pce_pitch_run.argtypes = [vp, C.POINTER(PitchParams), vp, i32]
     lib.pce_pitch_fetch.argtypes = [vp, vp, vp, vp]
+    lib.pce_stats_enqueue.argtypes = [vp, i32]
+    lib.pce_stats_wait.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pce_stft_db_run.argtypes = [vp, i32, i32]
     lib.pce_stft_db_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_stft_db_fetch.argtypes = [vp, i32, vp]
@@ -281,6 +284,27 @@ class ProsodyEngine:
     def pitch(self, slices, params: PitchParams, want_f0=True, want_strength=False):
         self.pitch_run(slices, params)
         return self.pitch_fetch(want_f0, want_strength)
+
+    def stats_enqueue(self, slot: int = 0):
+        """Queue the device-to-host copies of the last energy / LUFS / pitch-summary results behind their
+        runs and return at once; ``stats_wait(slot)`` collects them.  Two slots: the next batch can be
+        launched before this one's numbers are read."""
+        self._stat_n = getattr(self, "_stat_n", {})
+        self._stat_n[slot] = (getattr(self, "_en_n", None), getattr(self, "_lu_n", None),
+                              len(self._pi_slices) if getattr(self, "_pi_slices", None) is not None else None)
+        self._check(self._lib.pce_stats_enqueue(self._ctx, int(slot)))
+
+    def stats_wait(self, slot: int = 0):
+        """-> dict(energy=ENERGY_DTYPE[n] | None, lufs=(values, status) | None, pitch=SUMMARY_DTYPE[n] | None)."""
+        en_n, lu_n, pi_n = self._stat_n[slot]
+        en = np.zeros(en_n, dtype=ENERGY_DTYPE) if en_n is not None else None
+        lu = np.zeros(lu_n, dtype=np.float64) if lu_n is not None else None
+        st = np.zeros(lu_n, dtype=np.int32) if lu_n is not None else None
+        pi = np.zeros(pi_n, dtype=SUMMARY_DTYPE) if pi_n is not None else None
+        self._check(self._lib.pce_stats_wait(self._ctx, int(slot), en.ctypes.data if en is not None else None,
+                                             lu.ctypes.data if lu is not None else None, st.ctypes.data if st is not None else None,
+                                             pi.ctypes.data if pi is not None else None))
+        return {"energy": en, "lufs": (lu, st) if lu is not None else None, "pitch": pi}
 
     def stft_db_run(self, n_fft: int = 1024, hop: int = 256):
         self._check(self._lib.pce_stft_db_run(self._ctx, int(n_fft), int(hop)))

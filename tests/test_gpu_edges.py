@@ -125,3 +125,24 @@ def test_full_size_batch_properties(engine):
     engine.stft_db_run(1024, 256)
     s0 = engine.stft_db_fetch(0)
     assert s0.shape == (513, 626) and s0.max() == 0.0 and s0.min() >= -80.0
+
+
+@pytest.mark.gpu
+def test_async_stats_match_the_synchronous_fetches(engine, synth16k):
+    """pce_stats_enqueue / pce_stats_wait return the numbers of pce_energy_fetch / pce_lufs_fetch /
+    pce_pitch_fetch, also when a second batch of launches is already queued behind the copies."""
+    import prosody_control_french_tts_amd as pkg
+    eng = engine
+    eng.upload(synth16k, 16000)
+    sl = eng.whole_clip_slices()
+    params = pkg.PitchParams.praat(150.0, 600.0)
+    eng.energy_run(sl, 500); eng.lufs_run(sl); eng.pitch_run(sl, params)
+    eng.stats_enqueue(0)
+    eng.energy_run(sl, 500); eng.lufs_run(sl); eng.pitch_run(sl, params)      # next batch already in flight
+    eng.stats_enqueue(1)
+    a = eng.stats_wait(0); b = eng.stats_wait(1)
+    en = eng.energy_fetch(); lu, st = eng.lufs_fetch(); pi = eng.pitch_fetch(want_f0=False)["summary"]
+    for r in (a, b):
+        assert r["energy"].tobytes() == en.tobytes()
+        assert r["lufs"][0].tobytes() == lu.tobytes() and (r["lufs"][1] == st).all()
+        assert r["pitch"].tobytes() == pi.tobytes()
