@@ -12,7 +12,7 @@
 //     state_end(chunk) = A^len * state_begin(chunk) + zero_state_response_end(chunk)
 // and three passes make every chunk independent:
 //   k_lufs_pass1  one thread per chunk: run the cascade from a zero state, keep the end state
-//   k_lufs_scan   one thread per slice: propagate true begin states through its chunks
+//   k_lufs_scan   one wavefront per slice: propagate true begin states through its chunks (grouped scan)
 //   k_lufs_pass2  one thread per chunk: run again from the true state, sum y^2
 //   k_lufs_gate   one thread per slice: block energies = sums of whole chunks, gating, LUFS
 // All arithmetic is fp64 with contraction off.  Bound: fp64 VALU (about 70 dependent
@@ -99,9 +99,22 @@ __device__ __forceinline__ double lu_readlane_f64(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// One wavefront per slice.  The 64 lanes fetch 64 chunk end-states with one coalesced load
-// each; the (inherently sequential) propagation then runs wave-uniform with v_readlane
-// broadcasts, so the chain never waits on memory.
+// One wavefront per slice, three levels (the plain chain over a 10 s slice is 625 dependent 4x4
+// matrix-vector steps; this is 16 + n_groups + 16):
+//   1. lane g folds its group of LU_GROUP consecutive chunks from a zero state: z_g, and the
+//      group's transition matrix M_g = prod A^len;
+//   2. the group begin-states s_(g+1) = M_g s_g + z_g are chained wave-uniform (v_readlane);
+//   3. lane g replays its group from s_g and writes every chunk's begin state.
+constexpr int LU_GROUP = 16;
+__device__ __forceinline__ void lu_matvec(const double *__restrict__ m, double &s0, double &s1, double &s2, double &s3,
+                                          double e0, double e1, double e2, double e3)
+{
+    const double n0 = (fma(m[1], s1, fma(m[0], s0, e0))) + (fma(m[3], s3, m[2] * s2));
+    const double n1 = (fma(m[5], s1, fma(m[4], s0, e1))) + (fma(m[7], s3, m[6] * s2));
+    const double n2 = (fma(m[9], s1, fma(m[8], s0, e2))) + (fma(m[11], s3, m[10] * s2));
+    const double n3 = (fma(m[13], s1, fma(m[12], s0, e3))) + (fma(m[15], s3, m[14] * s2));
+    s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+}
 __global__ __launch_bounds__(64) void k_lufs_scan(const LuSlice *__restrict__ slices, const LuChunk *__restrict__ chunks, int n_slices,
                                                   const double *__restrict__ apow /* [LU_LMAX+1][16] */,
                                                   const double *__restrict__ state_end, double *__restrict__ state_init)
@@ -110,36 +123,53 @@ __global__ __launch_bounds__(64) void k_lufs_scan(const LuSlice *__restrict__ sl
     if (i >= n_slices) return;
     const int lane = threadIdx.x;
     const LuSlice s = slices[i];
-    double st0 = 0.0, st1 = 0.0, st2 = 0.0, st3 = 0.0;
-    double m[16]; int cur_len = -1;
-    for (int c0 = 0; c0 < s.n_chunks; c0 += 64) {
-        const int cnt = min(64, s.n_chunks - c0);
-        const size_t ci = (size_t)(s.first_chunk + c0 + lane);
-        const bool valid = lane < cnt;
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0; int len = 0;
-        if (valid) {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;                      // state at the start of the current 64-group block
+    for (int g0 = 0; g0 * LU_GROUP < s.n_chunks; g0 += 64) {
+        const int g = g0 + lane;
+        const int cb = g * LU_GROUP, ce = min(cb + LU_GROUP, s.n_chunks);   // this lane's chunks [cb, ce)
+        // level 1: zero-state response and transition matrix of the group
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+        double M[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) M[t] = (t % 5 == 0) ? 1.0 : 0.0;
+        for (int c = cb; c < ce; c++) {
+            const size_t ci = (size_t)(s.first_chunk + c);
             const double *e = state_end + 4 * ci;
-            e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3];
-            len = chunks[ci].len;
+            const double *a = apow + (size_t)chunks[ci].len * 16;
+            double A[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) A[t] = a[t];
+            lu_matvec(A, z0, z1, z2, z3, e[0], e[1], e[2], e[3]);
+            double N[16];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    N[r * 4 + q] = fma(A[r * 4 + 1], M[4 + q], A[r * 4] * M[q]) + fma(A[r * 4 + 3], M[12 + q], A[r * 4 + 2] * M[8 + q]);
+#pragma unroll
+            for (int t = 0; t < 16; t++) M[t] = N[t];
         }
-        double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
-        for (int q = 0; q < cnt; q++) {
-            if (lane == q) { o0 = st0; o1 = st1; o2 = st2; o3 = st3; }
-            const int lq = __builtin_amdgcn_readlane(len, q);
-            if (lq != cur_len) {
-                for (int t = 0; t < 16; t++) m[t] = apow[(size_t)lq * 16 + t];
-                cur_len = lq;
-            }
-            const double q0 = lu_readlane_f64(e0, q), q1 = lu_readlane_f64(e1, q), q2 = lu_readlane_f64(e2, q), q3 = lu_readlane_f64(e3, q);
-            const double n0 = (((m[0] * st0 + m[1] * st1) + m[2] * st2) + m[3] * st3) + q0;
-            const double n1 = (((m[4] * st0 + m[5] * st1) + m[6] * st2) + m[7] * st3) + q1;
-            const double n2 = (((m[8] * st0 + m[9] * st1) + m[10] * st2) + m[11] * st3) + q2;
-            const double n3 = (((m[12] * st0 + m[13] * st1) + m[14] * st2) + m[15] * st3) + q3;
-            st0 = n0; st1 = n1; st2 = n2; st3 = n3;
+        // level 2: begin state of every group of this block (wave-uniform chain over the lanes)
+        const int ng = min(64, (s.n_chunks - g0 * LU_GROUP + LU_GROUP - 1) / LU_GROUP);
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        for (int q = 0; q < ng; q++) {
+            if (lane == q) { b0 = c0; b1 = c1; b2 = c2; b3 = c3; }
+            double Mq[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) Mq[t] = lu_readlane_f64(M[t], q);
+            lu_matvec(Mq, c0, c1, c2, c3, lu_readlane_f64(z0, q), lu_readlane_f64(z1, q), lu_readlane_f64(z2, q), lu_readlane_f64(z3, q));
         }
-        if (valid) {
+        // level 3: replay the group from its true begin state
+        for (int c = cb; c < ce; c++) {
+            const size_t ci = (size_t)(s.first_chunk + c);
             double *o = state_init + 4 * ci;
-            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+            o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3;
+            const double *e = state_end + 4 * ci;
+            const double *a = apow + (size_t)chunks[ci].len * 16;
+            double A[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) A[t] = a[t];
+            lu_matvec(A, b0, b1, b2, b3, e[0], e[1], e[2], e[3]);
         }
     }
 }
