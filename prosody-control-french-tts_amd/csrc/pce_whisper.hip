@@ -451,7 +451,8 @@ __device__ __forceinline__ void stage_kv(const bf16 *__restrict__ kbase, int64_t
 
 __global__ __launch_bounds__(256) void k_attention(AttnArgs A)
 {
-    __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * 64 * 64];        // [stage][K | V^T][64][64] = 32 KiB
+    constexpr int AT_STAGES = 3;                                                 // two K/V^T tiles in flight behind the one being consumed
+    __shared__ __attribute__((aligned(1024))) bf16 smem[AT_STAGES * 2 * 64 * 64];        // [stage][K | V^T][64][64] = 48 KiB
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, clip = blockIdx.z;
@@ -482,12 +483,19 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs A)
     const int nt = (k_need + 63) / 64;
     const int my_q = q0 + r;
     stage_kv(kbase, A.k_ld, 0, Sk - 1, vtbase, A.vt_sp, smem, smem + 64 * 64, wv, lane);
+    if (nt > 1) stage_kv(kbase, A.k_ld, 64, Sk - 1, vtbase, A.vt_sp, smem + 2 * 64 * 64, smem + 3 * 64 * 64, wv, lane);
     for (int kt = 0; kt < nt; kt++) {
-        const bf16 *sK = smem + (kt & 1) * (2 * 64 * 64), *sVt = sK + 64 * 64;
-        __syncthreads();                                          // tile kt landed (vmcnt(0)), tile kt-1 consumed
-        if (kt + 1 < nt) {
-            bf16 *nK = smem + ((kt + 1) & 1) * (2 * 64 * 64);
-            stage_kv(kbase, A.k_ld, (kt + 1) * 64, Sk - 1, vtbase, A.vt_sp, nK, nK + 64 * 64, wv, lane);
+        const bf16 *sK = smem + (kt % AT_STAGES) * (2 * 64 * 64), *sVt = sK + 64 * 64;
+        // tile kt must have LANDED before anyone reads it: the compiler does not order LDS-DMA against the barrier
+        // (the ISA had no vmcnt wait inside this loop; a leaner loop body exposed the race as NaNs), so wait here
+        // Each wave issues 4 DMA instructions per tile, in tile order: tile kt has landed once at most the 4
+        // youngest (tile kt+1) are outstanding.
+        if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // tile kt landed for every wave, tile kt-1 consumed
+        if (kt + 2 < nt) {                                        // refill the stage tile kt-1 has just released
+            bf16 *nK = smem + ((kt + 2) % AT_STAGES) * (2 * 64 * 64);
+            stage_kv(kbase, A.k_ld, (kt + 2) * 64, Sk - 1, vtbase, A.vt_sp, nK, nK + 64 * 64, wv, lane);
         }
         // S^T for the two 32-key halves of the tile
         f32x16 st[2];
@@ -502,36 +510,68 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs A)
                 st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s4], st[u], 0, 0, 0);
             }
         }
-        // online softmax over this lane's query column: rows (keys) live in the registers of the two lane halves
+        // online softmax over this lane's query column: rows (keys) live in the registers of the two lane halves.
+        // The softmax arithmetic, not the MFMAs, bounded this kernel (PMC: 44 VALU instructions per MFMA), so
+        // interior tiles take a lean path: no visibility tests, the scale folded into the exponent's FMA
+        // (exp2(s c - m)), raw v_exp_f32, and the accumulator rescale only when some lane's maximum moved.
+        const bool edge = (kt * 64 + 63 >= Sk) || (A.causal && kt * 64 + 63 > q0);      // wave-uniform
         float mx = -1e30f;
+        if (!edge) {
+            float m0 = st[0][0], m1 = st[0][1], m2 = st[1][0], m3 = st[1][1];
 #pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int rho = (e & 3) + 8 * (e >> 2) + 4 * h;                       // accumulator row
-                const int key = kt * 64 + u * 32 + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
-                const bool vis = key < Sk && (!A.causal || key <= my_q);
-                const float v = vis ? st[u][e] * sl2 : -1e30f;
-                st[u][e] = v; mx = fmaxf(mx, v);
+            for (int e = 2; e < 16; e += 2) {
+                m0 = fmaxf(m0, st[0][e]); m1 = fmaxf(m1, st[0][e + 1]); m2 = fmaxf(m2, st[1][e]); m3 = fmaxf(m3, st[1][e + 1]);
             }
+            mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)) * sl2;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int rho = (e & 3) + 8 * (e >> 2) + 4 * h;                       // accumulator row
+                    const int key = kt * 64 + u * 32 + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
+                    const bool vis = key < Sk && (!A.causal || key <= my_q);
+                    const float v = vis ? st[u][e] : -1e30f;                              // (unscaled; -1e30 c is still hugely negative)
+                    st[u][e] = v; mx = fmaxf(mx, v);
+                }
+            mx = mx > -1e29f ? mx * sl2 : -1e30f;
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float corr = exp2f(m_run - m_new);
-        float sum = 0.f;
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float corr = __builtin_amdgcn_exp2f(m_run - m_new);                      // exactly 1 where the maximum stayed
+            l_run *= corr;
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+            for (int t = 0; t < 2; t++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const float pe = st[u][e] > -1e29f ? exp2f(st[u][e] - m_new) : 0.f;    // a fully masked tile must add nothing
-                st[u][e] = pe; sum += pe;
-            }
+                for (int e = 0; e < 16; e++) o[t][e] *= corr;
+            m_run = m_new;
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (!edge) {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(st[u][e], sl2, -m_run)), p1 = __builtin_amdgcn_exp2f(fmaf(st[u][e + 1], sl2, -m_run));
+                    st[u][e] = p0; st[u][e + 1] = p1;
+                    if (u == 0) { s0 += p0; s1 += p1; } else { s2 += p0; s3 += p1; }
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    // a masked key must add nothing, also when the whole tile is masked (m_run still -1e30)
+                    const float p0 = st[u][e] > -1e29f ? __builtin_amdgcn_exp2f(fmaf(st[u][e], sl2, -m_run)) : 0.f;
+                    const float p1 = st[u][e + 1] > -1e29f ? __builtin_amdgcn_exp2f(fmaf(st[u][e + 1], sl2, -m_run)) : 0.f;
+                    st[u][e] = p0; st[u][e + 1] = p1;
+                    if (u == 0) { s0 += p0; s1 += p1; } else { s2 += p0; s3 += p1; }
+                }
+        }
+        float sum = (s0 + s1) + (s2 + s3);
         sum += __shfl_xor(sum, 32, 64);
-        l_run = l_run * corr + sum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) o[t][e] *= corr;
+        l_run += sum;
         // O^T += V^T P^T : k-step (u, s2) covers keys u*32 + 16 s2 .. +15 (in pi order); B = registers 8 s2 .. 8 s2 + 7
 #pragma unroll
         for (int u = 0; u < 2; u++)
