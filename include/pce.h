@@ -227,6 +227,17 @@ int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32
 int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32_t batch, int32_t *path_i, int32_t *path_j,
             int32_t *path_len);
 
+/* ---- batched Needleman-Wunsch word alignment ------------------------------
+ * Replaces needleman_wunsch (Code/Pipeline/NeedlemanWunschAlignement.py:27-81) for a batch of sequence pairs.
+ * Pair b aligns a_ids[a_off[b] .. a_off[b+1]) (rows, at most 1024) with b_ids[b_off[b] .. b_off[b+1]); the ids are
+ * the host's integer codes of the normalised tokens (:43-47), equal ids = equal tokens.  Scores as the reference's
+ * keyword arguments (match 1, mismatch -1, gap -1).  Output for pair b starts at element
+ * sum_{p<b} (len_a[p] + len_b[p]) of out_i / out_j and has out_len[b] steps in alignment order: (i, j) = a
+ * diagonal step, (i, -1) a gap in the second sequence, (-1, j) a gap in the first; ties resolve diagonal > up >
+ * left as the reference's trace-back does (:69-80).  Integer arithmetic: identical alignments. */
+int pce_nw_align(pce_ctx *ctx, const int32_t *a_ids, const int64_t *a_off, const int32_t *b_ids, const int64_t *b_off, int32_t batch,
+                 int32_t match, int32_t mismatch, int32_t gap, int32_t *out_i, int32_t *out_j, int32_t *out_len);
+
 /* ---- asynchronous statistics fetch ---------------------------------------
  * The per-slice numbers of the last pce_energy_run / pce_lufs_run / pce_pitch_run are what the reference's
  * driver consumes per utterance (Code/audioPipeline.py:380-400) and what the sharded driver all-gathers
@@ -244,7 +255,7 @@ enum pce_kernel_id {
     PCE_K_ENERGY = 0,
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
-    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN,
+    PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN, PCE_K_NW,
     PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);

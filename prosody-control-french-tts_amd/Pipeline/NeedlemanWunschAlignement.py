@@ -4,8 +4,12 @@
 Needleman-Wunsch with match +1 / mismatch -1 / gap -1 over the ``Text`` column, comparison
 after the reference's token normalisation (the five characters ß ? . , ; are stripped and the
 token is lower-cased *only when one of them was present*, :43-47), trace-back preference
-diagonal > up > left (:69-80), output line format of :104.  Integer DP on the host; the
-scoring matrix is filled with numpy one anti-dependency row at a time."""
+diagonal > up > left (:69-80), output line format of :104.
+
+``needleman_wunsch_alignement`` (the directory-level entry point of the legacy pipeline) aligns every
+file pair of the run in ONE launch of the engine's batched integer kernel (``pce_nw_align``); the host
+only normalises tokens to integer ids and formats the result.  ``needleman_wunsch`` is the host
+restatement of a single alignment, kept for the golden-vector tests (integer DP, numpy row fill)."""
 import csv
 import os
 import sys
@@ -60,20 +64,34 @@ def needleman_wunsch(seq1, seq2, match_score=1, mismatch_score=-1, gap_penalty=-
     return a1[::-1], a2[::-1]
 
 
+def needleman_wunsch_batch(pairs, engine=None, match_score=1, mismatch_score=-1, gap_penalty=-1):
+    """All (seq1, seq2) pairs in one ``pce_nw_align`` launch -> [(aligned1, aligned2), ...]."""
+    if engine is None:
+        from ..engine import get_default_engine
+        engine = get_default_engine()
+    vocab = {}
+
+    def ids(seq):
+        return [vocab.setdefault(_norm(w[1]), len(vocab)) for w in seq]
+
+    res = engine.nw_align([(ids(a), ids(b)) for a, b in pairs], match_score, mismatch_score, gap_penalty)
+    return [([a[i] if i >= 0 else _GAP for i in ii], [b[j] if j >= 0 else _GAP for j in jj]) for (a, b), (ii, jj) in zip(pairs, res)]
+
+
 def format_alignment(aligned):
     return "".join(f"{d1[0]}: {d1[1]} ({d1[2]}-{d1[3]}, {d1[4]}) || {d2[0]}: {d2[1]} ({d2[2]}-{d2[3]}, {d2[4]})\n"
                    for d1, d2 in zip(*aligned))
 
 
-def needleman_wunsch_alignement(in_needleman_wunsch_microsoft, in_needleman_wunsch, AligNeedlemanWhunch_out):
+def needleman_wunsch_alignement(in_needleman_wunsch_microsoft, in_needleman_wunsch, AligNeedlemanWhunch_out, engine=None):
     datatype = "Segments"
     d_syn = os.path.join(in_needleman_wunsch_microsoft, datatype)
     d_nat = os.path.join(in_needleman_wunsch, datatype)
     out = os.path.join(AligNeedlemanWhunch_out, datatype)
     os.makedirs(out, exist_ok=True)
-    for name in sorted(set(os.listdir(d_syn)).intersection(os.listdir(d_nat))):
-        aligned = needleman_wunsch(_read_segments_from_csv2(os.path.join(d_syn, name)),
-                                   _read_segments_from_csv2(os.path.join(d_nat, name)))
+    names = sorted(set(os.listdir(d_syn)).intersection(os.listdir(d_nat)))
+    pairs = [(_read_segments_from_csv2(os.path.join(d_syn, name)), _read_segments_from_csv2(os.path.join(d_nat, name))) for name in names]
+    for name, aligned in zip(names, needleman_wunsch_batch(pairs, engine) if pairs else []):
         with open(os.path.join(out, f"aligned_{name[:-4]}.txt"), "w", encoding="utf-8") as f:
             f.write(format_alignment(aligned))
 

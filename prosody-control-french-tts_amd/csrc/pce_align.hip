@@ -12,6 +12,7 @@
 // previous diagonals live in LDS (double buffered), the 1-byte trace goes to global memory and is walked
 // back by one lane.  N <= 1024 rows (Whisper: <= 448 tokens), any number of columns.
 #include "pce_internal.h"
+#include <vector>
 
 namespace {
 
@@ -73,6 +74,67 @@ __global__ __launch_bounds__(DTW_MAXN) void k_dtw(const double *__restrict__ x, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Batched Needleman-Wunsch word alignment (legacy Pipeline, Code/Pipeline/NeedlemanWunschAlignement.py:27-81):
+// score[i][j] = max(score[i-1][j-1] + (a_i == b_j ? match : mismatch), score[i-1][j] + gap, score[i][j-1] + gap),
+// score[i][0] = i gap, score[0][j] = j gap; the trace-back tests "diagonal, then up, else left" (:69-80) against
+// the finished matrix, which is the same as recording, per cell, the FIRST of (diagonal, up, left) that attains the
+// maximum.  Tokens are compared on the host-normalised integer ids.  Integer arithmetic: the alignment is exactly
+// the reference's.  Same wavefront as k_dtw: one workgroup per pair, thread = row, two previous anti-diagonals in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DTW_MAXN) void k_nw(const int *__restrict__ a_ids, const long long *__restrict__ a_off, const int *__restrict__ b_ids,
+                                                const long long *__restrict__ b_off, int match, int mismatch, int gap,
+                                                unsigned char *__restrict__ trace, const long long *__restrict__ tr_off,
+                                                int *__restrict__ out_i, int *__restrict__ out_j, const long long *__restrict__ out_off,
+                                                int *__restrict__ out_len)
+{
+    __shared__ int diag[3][DTW_MAXN + 1];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int N = (int)(a_off[b + 1] - a_off[b]), M = (int)(b_off[b + 1] - b_off[b]);
+    const int *A = a_ids + a_off[b], *B = b_ids + b_off[b];
+    unsigned char *tr = trace + tr_off[b];                // [(N+1) x (M+1)]
+    // diagonal D holds score[r][D - r]; thread t owns row r = t + 1, row 0 is the boundary
+    const int r = t + 1;
+    const int my_a = t < N ? A[t] : 0;
+    if (t == 0) { diag[0][0] = 0; diag[1][0] = gap; }    // score[0][0], score[0][1]
+    if (t < N && r == 1) diag[1][1] = gap;               // score[1][0]
+    __syncthreads();
+    for (int D = 2; D <= N + M; D++) {
+        int *cur = diag[D % 3]; const int *p1 = diag[(D - 1) % 3], *p2 = diag[(D - 2) % 3];
+        const int c = D - r;
+        if (t < N) {
+            if (c >= 1 && c <= M) {
+                const int dg = p2[r - 1] + (my_a == B[c - 1] ? match : mismatch), up = p1[r - 1] + gap, lf = p1[r] + gap;
+                int best = dg; unsigned char tt = 0;
+                if (up > best) { best = up; tt = 1; }
+                if (lf > best) { best = lf; tt = 2; }
+                cur[r] = best;
+                tr[(size_t)r * (M + 1) + c] = tt;
+            } else if (c == 0) {
+                cur[r] = r * gap;                         // score[r][0]
+            }
+        }
+        if (t == 0 && D <= M) cur[0] = D * gap;           // score[0][D]
+        __syncthreads();
+    }
+    __threadfence_block();
+    if (t == 0) {
+        int i = N, j = M, n = 0;
+        int *pi = out_i + out_off[b], *pj = out_j + out_off[b];
+        while (i > 0 || j > 0) {
+            const int tt = (i == 0) ? 2 : (j == 0) ? 1 : tr[(size_t)i * (M + 1) + j];
+            if (tt == 0) { pi[n] = i - 1; pj[n] = j - 1; i--; j--; }
+            else if (tt == 1) { pi[n] = i - 1; pj[n] = -1; i--; }
+            else { pi[n] = -1; pj[n] = j - 1; j--; }
+            n++;
+        }
+        for (int x = 0, z = n - 1; x < z; x++, z--) {
+            const int ti = pi[x], tj = pj[x]; pi[x] = pi[z]; pj[x] = pj[z]; pi[z] = ti; pj[z] = tj;
+        }
+        out_len[b] = n;
+    }
+}
+
 } // namespace
 
 // device-resident batch (used by the Whisper alignment path): all pointers are device pointers
@@ -109,6 +171,55 @@ int pce_dtw(pce_ctx *c, const double *x, int32_t n_rows, int32_t n_cols, int32_t
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
     dx.release(); dtr.release(); dpi.release(); dpj.release(); dpl.release();
+    return PCE_OK;
+}
+
+int pce_nw_align(pce_ctx *c, const int32_t *a_ids, const int64_t *a_off, const int32_t *b_ids, const int64_t *b_off, int32_t batch,
+                 int32_t match, int32_t mismatch, int32_t gap, int32_t *out_i, int32_t *out_j, int32_t *out_len)
+{
+    if (!c || !a_off || !b_off || !out_i || !out_j || !out_len || batch <= 0) return PCE_E_INVALID;
+    PCE_HIP(c, hipSetDevice(c->device));
+    std::vector<long long> tro((size_t)batch + 1, 0), oo((size_t)batch + 1, 0);
+    int max_rows = 0;
+    for (int32_t b = 0; b < batch; b++) {
+        const int64_t n = a_off[b + 1] - a_off[b], m = b_off[b + 1] - b_off[b];
+        if (n < 0 || m < 0) return pce_fail(c, PCE_E_INVALID, "pce_nw_align: offsets of pair %d decrease", b);
+        if (n > DTW_MAXN) return pce_fail(c, PCE_E_LIMIT, "pce_nw_align: pair %d has %lld rows (limit %d)", b, (long long)n, DTW_MAXN);
+        tro[(size_t)b + 1] = tro[(size_t)b] + (n + 1) * (m + 1);
+        oo[(size_t)b + 1] = oo[(size_t)b] + n + m;
+        if (n > max_rows) max_rows = (int)n;
+    }
+    const size_t na = (size_t)a_off[batch], nb = (size_t)b_off[batch], no = (size_t)oo[(size_t)batch];
+    if (a_off[0] != 0 || b_off[0] != 0) return pce_fail(c, PCE_E_INVALID, "pce_nw_align: offsets must start at 0");
+    if ((na && !a_ids) || (nb && !b_ids)) return PCE_E_INVALID;
+    DevBuf da, db, dao, dbo, dtr, dtro, doi, doj, doo, dol;
+    PCE_HIP(c, da.reserve(sizeof(int) * (na + 1))); PCE_HIP(c, db.reserve(sizeof(int) * (nb + 1)));
+    PCE_HIP(c, dao.reserve(sizeof(long long) * ((size_t)batch + 1))); PCE_HIP(c, dbo.reserve(sizeof(long long) * ((size_t)batch + 1)));
+    PCE_HIP(c, dtr.reserve((size_t)tro[(size_t)batch] + 1)); PCE_HIP(c, dtro.reserve(sizeof(long long) * ((size_t)batch + 1)));
+    PCE_HIP(c, doi.reserve(sizeof(int) * (no + 1))); PCE_HIP(c, doj.reserve(sizeof(int) * (no + 1)));
+    PCE_HIP(c, doo.reserve(sizeof(long long) * ((size_t)batch + 1))); PCE_HIP(c, dol.reserve(sizeof(int) * (size_t)batch));
+    if (na) PCE_HIP(c, hipMemcpyAsync(da.p, a_ids, sizeof(int) * na, hipMemcpyHostToDevice, c->stream));
+    if (nb) PCE_HIP(c, hipMemcpyAsync(db.p, b_ids, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dao.p, a_off, sizeof(long long) * ((size_t)batch + 1), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dbo.p, b_off, sizeof(long long) * ((size_t)batch + 1), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dtro.p, tro.data(), sizeof(long long) * tro.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(doo.p, oo.data(), sizeof(long long) * oo.size(), hipMemcpyHostToDevice, c->stream));
+    int threads = 64; while (threads < max_rows) threads <<= 1;
+    {
+        KernelTimer t(c, PCE_K_NW);
+        hipLaunchKernelGGL(k_nw, dim3((unsigned)batch), dim3((unsigned)threads), 0, c->stream, da.as<int>(), dao.as<long long>(), db.as<int>(),
+                           dbo.as<long long>(), match, mismatch, gap, dtr.as<unsigned char>(), dtro.as<long long>(), doi.as<int>(), doj.as<int>(),
+                           doo.as<long long>(), dol.as<int>());
+    }
+    PCE_HIP(c, hipGetLastError());
+    if (no) {
+        PCE_HIP(c, hipMemcpyAsync(out_i, doi.p, sizeof(int) * no, hipMemcpyDeviceToHost, c->stream));
+        PCE_HIP(c, hipMemcpyAsync(out_j, doj.p, sizeof(int) * no, hipMemcpyDeviceToHost, c->stream));
+    }
+    PCE_HIP(c, hipMemcpyAsync(out_len, dol.p, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    for (DevBuf *x : {&da, &db, &dao, &dbo, &dtr, &dtro, &doi, &doj, &doo, &dol}) x->release();
     return PCE_OK;
 }
 

@@ -81,7 +81,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -90,7 +90,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch",
+           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch",
            "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
@@ -119,6 +119,7 @@ def load_library() -> C.CDLL:
     lib.pce_pitch_run.argtypes = [vp, C.POINTER(PitchParams), vp, i32]
     lib.pce_pitch_fetch.argtypes = [vp, vp, vp, vp]
     lib.pce_stats_enqueue.argtypes = [vp, i32]
+    lib.pce_nw_align.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.pce_stats_wait.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pce_stft_db_run.argtypes = [vp, i32, i32]
     lib.pce_stft_db_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -403,6 +404,20 @@ class ProsodyEngine:
         pi = np.zeros((b, n + m), dtype=np.int32); pj = np.zeros((b, n + m), dtype=np.int32); pl = np.zeros(b, dtype=np.int32)
         self._check(self._lib.pce_dtw(self._ctx, x.ctypes.data, n, m, b, pi.ctypes.data, pj.ctypes.data, pl.ctypes.data))
         return [(pi[k, :pl[k]].copy(), pj[k, :pl[k]].copy()) for k in range(b)]
+
+    def nw_align(self, pairs, match=1, mismatch=-1, gap=-1):
+        """Batched Needleman-Wunsch over integer token ids: ``pairs`` = [(ids_a, ids_b), ...] ->
+        [(i_idx, j_idx), ...] with -1 marking a gap (alignment order)."""
+        la = np.array([len(a) for a, _ in pairs], dtype=np.int64); lb = np.array([len(b) for _, b in pairs], dtype=np.int64)
+        ao = np.zeros(len(pairs) + 1, dtype=np.int64); bo = np.zeros(len(pairs) + 1, dtype=np.int64)
+        np.cumsum(la, out=ao[1:]); np.cumsum(lb, out=bo[1:])
+        a = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int32) for x, _ in pairs] + [np.zeros(0, np.int32)]))
+        b = np.ascontiguousarray(np.concatenate([np.asarray(y, dtype=np.int32) for _, y in pairs] + [np.zeros(0, np.int32)]))
+        oo = np.zeros(len(pairs) + 1, dtype=np.int64); np.cumsum(la + lb, out=oo[1:])
+        oi = np.zeros(max(int(oo[-1]), 1), dtype=np.int32); oj = np.zeros_like(oi); ol = np.zeros(len(pairs), dtype=np.int32)
+        self._check(self._lib.pce_nw_align(self._ctx, a.ctypes.data, ao.ctypes.data, b.ctypes.data, bo.ctypes.data, len(pairs),
+                                           int(match), int(mismatch), int(gap), oi.ctypes.data, oj.ctypes.data, ol.ctypes.data))
+        return [(oi[oo[k]:oo[k] + ol[k]].copy(), oj[oo[k]:oo[k] + ol[k]].copy()) for k in range(len(pairs))]
 
     # ---------------------------------------------------------------- measurement
     def profile_enable(self, on=True):

@@ -146,3 +146,28 @@ def test_async_stats_match_the_synchronous_fetches(engine, synth16k):
         assert r["energy"].tobytes() == en.tobytes()
         assert r["lufs"][0].tobytes() == lu.tobytes() and (r["lufs"][1] == st).all()
         assert r["pitch"].tobytes() == pi.tobytes()
+
+
+@pytest.mark.gpu
+def test_nw_align_gpu_reproduces_the_reference_alignments(engine, tmp_path):
+    """pce_nw_align (one launch for the whole batch) gives the text of the reference's own runs (golden G2),
+    plus ragged / empty / tie-heavy pairs against the host restatement."""
+    import json, os
+    from prosody_control_french_tts_amd.Pipeline import NeedlemanWunschAlignement as NW
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "needleman_wunsch.json")))
+    tup = lambda rows: [(r["PhraseID"], r["Text"], float(r["Start"]), float(r["End"]), float(r["Duration"])) for r in rows]
+    pairs = [(tup(c["seq1"]), tup(c["seq2"])) for c in cases]
+    got = NW.needleman_wunsch_batch(pairs, engine)
+    for c, g in zip(cases, got):
+        assert NW.format_alignment(g) == c["expected_text"]
+    rng = np.random.default_rng(5)
+    words = ["le", "la", "chat", "Chat.", "mange", "souris,", "une", "et", "ß", "oui?"]
+    extra = []
+    for n, m in [(0, 0), (0, 5), (7, 0), (1, 1), (40, 37), (300, 280), (64, 65)]:
+        mk = lambda k: [(str(i), words[int(rng.integers(len(words)))], float(i), float(i) + 0.5, 0.5) for i in range(k)]
+        extra.append((mk(n), mk(m)))
+    for (a, b), g in zip(extra, NW.needleman_wunsch_batch(extra, engine)):
+        if a and b:
+            assert NW.format_alignment(g) == NW.format_alignment(NW.needleman_wunsch(a, b))
+        else:       # the reference indexes seq[-1] of an empty list (IndexError); the kernel aligns everything to gaps
+            assert len(g[0]) == len(a) + len(b) and [w for w in g[0] if w[0] != "-"] == a and [w for w in g[1] if w[0] != "-"] == b
