@@ -14,6 +14,8 @@ pinned and every value they return is recorded in the fixture:
                            WAVs x ms windows (pydub stand-in = stdlib `wave` decode + pydub's slicing rule)
   G4 gate.json             Aligners/use_whisper_timestamped.WhisperTranscriber._check_audio_content
                            on the 10 demo WAVs + synthetic silence/noise (real scipy.io.wavfile)
+  G5 ssml_fragment.json    Pipeline/Get_Wav.create_ssml_fragment on a grid of (text, pitch, rate, loudness, pause)
+  G6 textgrid_text.json    Pipeline/utils.extract_clean_text_from_textgrid on hand-written TextGrid texts
   G7 tagger.json           audioPipeline.AudioPipeline.measure_prosody_and_build_ssml driven by
                            scripted measurements: pins syntagme construction, baselines, clamps,
                            EMA smoothing and the three CSV outputs (Code/audioPipeline.py:261-711)
@@ -344,7 +346,41 @@ def g7_tagger(TextGrid, Sound, Meter, POS, tmp):
     jdump("tagger.json", scenarios)
 
 
+# --------------------------------------------------------------------------- G5 / G6 (string formats of the legacy pipeline)
+def make_g5_g6():
+    """G5 ssml_fragment.json: Pipeline/Get_Wav.create_ssml_fragment on a grid (pause globals as get_wav sets them, :91-94).
+    G6 textgrid_text.json: Pipeline/utils.extract_clean_text_from_textgrid on hand-written TextGrid texts."""
+    gw = importlib.import_module("Pipeline.Get_Wav")
+    gw.pause_coef, gw.max_pause, gw.min_pause = 1.0, 500, 1
+    rng = np.random.default_rng(77)
+    texts = ["Bonjour", "oui,", "vraimentß", "non!", "pourquoi?", "fin.", "a<b & c>d", "tab\there", "", "   ", "mot;"]
+    cases = []
+    for text in texts:
+        for _ in range(6):
+            args = dict(text=text,
+                        pitch_adj=float(rng.choice([0.0, -0.0, 4.0, -9.0, 12.345, -0.3, 100.0])),
+                        rate_adj=float(rng.choice([0.0, 1.0, -1.0, 3.7, -25.0, 50.0, 0.31])),
+                        loudness_adj=float(rng.choice([0.0, 5.5, -12.25, 33.333])),
+                        duration_pause_syntagme_natural=float(rng.choice([0.0, float("nan"), 0.002, 0.25, 0.9, 3.0, 1.4999])),
+                        voice="fr-FR-HenriNeural", style=str(rng.choice(["", "cheerful"])), styledegree=2)
+            cases.append({"args": {k: (None if isinstance(v, float) and v != v else v) for k, v in args.items()},
+                          "expected": gw.create_ssml_fragment(**args)})
+    jdump("ssml_fragment.json", cases)
+    ut = importlib.import_module("Pipeline.utils")
+    grids = [
+        'File type = "ooTextFile"\n    intervals [1]:\n        xmin = 0\n        xmax = 0.5\n        text = "bonjour,"\n    intervals [2]:\n        text = " "\n    intervals [3]:\n        text = "le [rire] monde;"\n',
+        'text = ""\ntext = "a = b"\ntext = "[*]"\nname = "words"\n        text = "fin."\n',
+        "no text lines at all\n",
+        'text = "un, deux; trois [x][y] quatre"\n text = "..."\n',
+    ]
+    jdump("textgrid_text.json", [{"content": g, "expected": ut.extract_clean_text_from_textgrid(g)} for g in grids])
+
+
+
 def main():
+    if os.environ.get("PCE_GOLDEN_ONLY") == "g5g6":
+        make_g5_g6()
+        return
     os.environ["PYTHONHASHSEED"] = "0"
     if os.environ.get("_GOLDEN_CHILD") != "1":       # hash() seeds the scripted measurements: pin it
         os.environ["_GOLDEN_CHILD"] = "1"
@@ -369,7 +405,9 @@ def main():
         g3_rms(wavs)
         g4_gate(wavs, tmp)
         g7_tagger(TextGrid, Sound, Meter, POS, tmp)
+    make_g5_g6()
 
 
 if __name__ == "__main__":
     main()
+

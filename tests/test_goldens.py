@@ -140,3 +140,17 @@ def test_g7_tagger_csvs_identical(idx, tmp_path):
         p = tmp_path / name
         df.to_csv(p, index=False)
         assert p.read_text(encoding="utf-8") == sc["expected"][name], name
+
+
+def test_g5_ssml_fragment_strings_identical():
+    from prosody_control_french_tts_amd.Pipeline import Get_Wav as GW
+    for case in load("ssml_fragment.json"):
+        a = dict(case["args"])
+        a = {k: (float("nan") if v is None else v) for k, v in a.items()}
+        assert GW.create_ssml_fragment(**a) == case["expected"], case
+
+
+def test_g6_textgrid_text_extraction_identical():
+    from prosody_control_french_tts_amd.Pipeline import utils as U
+    for case in load("textgrid_text.json"):
+        assert U.extract_clean_text_from_textgrid(case["content"]) == case["expected"]

@@ -138,3 +138,34 @@ def test_stft_db_matches_oracle(engine, synth16k):
         assert np.max(np.abs(got[live] - want[live])) <= 2e-2
         # values at the floor agree up to the same band
         assert np.max(np.abs(got - want)) <= 0.25
+
+
+def test_c1_real_speech_clip_all_measurements(engine):
+    """BASELINE.json configs[0] (C1): the reference's demo recording segment_ph9 at 16 kHz, 5.000 s
+    (tests/golden/c1_segment_ph9_16k.npz: resampled with the engine's own polyphase spec, zero padded).
+    Real speech through every kernel of the prosody path, against the oracle at the tolerances above."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_segment_ph9_16k.npz"))
+    pcm, rate = z["pcm"], int(z["rate"])
+    assert rate == 16000 and len(pcm) == 80000
+    engine.upload([pcm], rate)
+    sl = engine.whole_clip_slices()
+    en = engine.energy(sl, 500)[0]
+    x64 = pcm.astype(np.int64)
+    assert en["sum_sq"] == int(np.sum(x64 * x64)) and en["peak_abs"] == int(np.max(np.abs(x64)))
+    rms, ratio, ok = H.gate_from_counts(int(en["sum_sq"]), int(en["n_loud"]), len(pcm))
+    assert (ratio, ok) == O.gate_check(pcm)[1:]
+    lu, st = engine.lufs(sl)
+    assert st[0] == E.SLICE_OK and abs(lu[0] - O.lufs_numpy(pcm.astype(float), rate)) <= 1e-6
+    res = engine.pitch(sl, E.PitchParams.praat(150.0, 600.0), want_f0=True)
+    want = O.pitch_ac(pcm.astype(np.float64) / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))
+    assert len(res["f0"]) == len(want["f0"]) == 997           # SURVEY 8a: 997 frames at 5 s
+    v = want["f0"] > 0
+    assert np.array_equal(res["f0"] > 0, v) and v.sum() > 100
+    assert np.max(np.abs(res["f0"][v] - want["f0"][v]) / want["f0"][v]) <= 1e-6
+    assert abs(res["summary"][0]["median_f0"] - float(np.median(want["f0"][v]))) <= 1e-6 * float(np.median(want["f0"][v]))
+    engine.stft_db_run(1024, 256)
+    got = engine.stft_db_fetch(0); ws = O.stft_db(pcm.astype(np.float32) / 32768.0)
+    assert got.shape == ws.shape == (513, 313)                # SURVEY 8a: 513 x 313 at 5 s
+    live = (ws > -79.9) & (got > -79.9)
+    assert np.max(np.abs(got[live] - ws[live])) <= 2e-2
