@@ -39,24 +39,45 @@ def load_pmc_traffic():
         return None
 
 
-def cpu_baseline(clips, rate, budget_clips):
-    """The CPU oracle ("port": C double-precision restatement, 1 thread) on a bounded sample."""
+def _cpu_one(args):
+    c, rate = args
     from oracle import oracle as O
+    x = c.astype(np.float64)
+    O.gate_check(c)
+    O.rms_db_int16_wrapped(c)
+    O.lufs_c(x, rate)
+    f0 = O.pitch_ac(x / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+    v = f0[f0 > 0]
+    _ = float(np.median(v)) if v.size else 0.0
+    O.stft_db(c.astype(np.float32) / 32768.0)
+    return len(c)
+
+
+def cpu_baseline(clips, rate, budget_clips):
+    """The CPU oracle ("port": C double-precision restatement) on a bounded sample: one thread (`value`, the
+    contract's figure) and, as `all_cores`, utterance-parallel over the host's cores the way the reference runs
+    one process per voice (config.yaml:58)."""
     sample = clips[:budget_clips]
     t0 = time.perf_counter()
     for c in sample:
-        x = c.astype(np.float64)
-        O.gate_check(c)
-        O.rms_db_int16_wrapped(c)
-        O.lufs_c(x, rate)
-        f0 = O.pitch_ac(x / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
-        v = f0[f0 > 0]
-        _ = float(np.median(v)) if v.size else 0.0
-        O.stft_db(c.astype(np.float32) / 32768.0)
+        _cpu_one((c, rate))
     dt = time.perf_counter() - t0
     secs = sum(len(c) for c in sample) / rate
-    return {"value": secs / dt, "unit": "audio-seconds/sec", "cores": 1, "kind": "port",
-            "sample": f"{len(sample)} of the same synthetic 10 s clips, oracle/pce_oracle.c + numpy, {dt:.1f} s of CPU time"}
+    out = {"value": secs / dt, "unit": "audio-seconds/sec", "cores": 1, "kind": "port",
+           "sample": f"{len(sample)} of the same synthetic 10 s clips, oracle/pce_oracle.c + numpy, {dt:.1f} s of CPU time"}
+    try:
+        # worker PROCESSES (fork): called before this process touches the GPU, see main()
+        import multiprocessing as mp
+        workers = max(1, min(len(sample), os.cpu_count() or 1, 64))
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_cpu_one, [(sample[0], rate)] * workers)      # start-up (library load) outside the timed part
+            t0 = time.perf_counter()
+            pool.map(_cpu_one, [(c, rate) for c in sample], chunksize=1)
+            dtp = time.perf_counter() - t0
+        out["all_cores"] = {"value": secs / dtp, "processes": workers, "host_cores": os.cpu_count(), "seconds": dtp}
+    except Exception as e:                                         # the single-thread figure is the contract's
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -80,6 +101,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rate = 16000
+    n_samples = int(round(args.seconds * rate))
+    # synthetic data of the workload's shape; rank r owns clips [r*clips, (r+1)*clips) (weak scaling)
+    clips = synth.synth_batch(args.clips, args.seconds, rate, first=rank * args.clips)
+    # CPU baseline first: its all-cores leg forks worker processes, which must happen before this process
+    # initialises the GPU
+    cpu = cpu_baseline(clips, rate, args.cpu_clips) if (rank == 0 and args.cpu_clips > 0) else None
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -87,12 +115,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    rate = 16000
-    n_samples = int(round(args.seconds * rate))
-
-    # synthetic data of the workload's shape; rank r owns clips [r*clips, (r+1)*clips) (weak scaling)
-    clips = synth.synth_batch(args.clips, args.seconds, rate, first=rank * args.clips)
-
     eng = pkg.ProsodyEngine(local_rank)
     eng.upload(clips, rate)                      # inputs resident in HBM before the timed region
     sl = eng.whole_clip_slices()
@@ -220,7 +242,6 @@ def main():
                         "note": "dominant stage by device time; `achieved` = the stage's algorithmic bytes (or flops) / the device time "
                                 "of the stage's kernels.  The F0 stage is fp64-VALU bound (about 1e3 flop per algorithmic byte, "
                                 "DESIGN.md section 3): its HBM fraction is small by construction; `stages` lists every stage."}
-        cpu = cpu_baseline(clips, rate, args.cpu_clips) if args.cpu_clips > 0 else None
         info = eng.device_info()
         print(json.dumps({
             "metric": "audio-seconds/sec prosody+align throughput, 16 kHz French",
