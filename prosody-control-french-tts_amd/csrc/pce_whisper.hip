@@ -206,7 +206,7 @@ template <int EPI>
 __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
                                                         const bf16 *__restrict__ B, int M, int N, int K,
                                                         const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
-                                                        const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles)
+                                                        const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles, unsigned long long *trace)
 {
     // operand ring [stage][A|B][128][64] bf16, re-used as the fp32 epilogue tile [128][G_TLD]
     constexpr int SMEM_ELEMS = (G_STAGES * 2 * G_BM * G_BK * 2 > G_BM * G_TLD * 4 ? G_STAGES * 2 * G_BM * G_BK : G_BM * G_TLD * 2);
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
         m0 = tm * G_BM; n0 = tn * G_BN;
         if (m0 >= M) return;                                                     // padding tile
     }
+    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0;
     A += (int64_t)blockIdx.z * a_batch;
     f32x4 acc[4][2];
 #pragma unroll
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+    const unsigned long long t_loop = trace ? __builtin_amdgcn_s_memtime() : 0;
     // epilogue.  The accumulator layout (col = lane & 15, row = (lane >> 4) * 4 + reg) would store 2-byte
     // elements 32 B at a time; measured, such an epilogue cost more than the whole K loop.  The tile
     // goes through LDS instead (the operand ring is free now) and leaves as full 256-B row segments.
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
             for (int r = 0; r < 4; r++)
                 tile[(wr * 64 + i * 16 + fq * 4 + r) * G_TLD + wc * 32 + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
+    const unsigned long long t_tile = trace ? __builtin_amdgcn_s_memtime() : 0;
     const int64_t cbase = (int64_t)blockIdx.z * c_batch;
     if (EPI == EPI_QKV && n0 >= v_col0) {
         // V columns: written transposed, vt[clip][head][d][key], so the attention kernel can stage V^T tiles
@@ -356,6 +359,11 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
             }
             *dst = o;
         }
+    }
+    if (trace && tid == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = t_start; o[1] = t_loop; o[2] = t_tile; o[3] = t_end;
     }
 }
 
@@ -870,6 +878,7 @@ int mel_setup(pce_ctx *c, WhisperState *w, int n_mels)
     return PCE_OK;
 }
 
+static unsigned long long *g_gemm_trace = nullptr;          // debugging aid: per-workgroup s_memtime stamps (tools only)
 template <int EPI>
 void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const bf16 *B, int M, int N, int K, const float *bias,
                  void *C, int64_t ldc, int64_t c_batch, int batch, const float *pos = nullptr, int pos_T = 1, int v_col0 = 0,
@@ -882,8 +891,29 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
     int sm = sm_env > 0 ? sm_env : 16;                     // 16 x sn measured best by a hair (645-656 TFLOP/s over 4..16 x 2..8)
     if (sn_env > 0 && tiles_n % sn_env == 0) sn = sn_env;
     dim3 grid((unsigned)tiles_n, (unsigned)(div_up(M, G_BM * sm) * sm), (unsigned)batch);
+    static const bool want_trace = getenv("PCE_GEMM_TRACE") != nullptr;
+    if (want_trace) {
+        const size_t nblk = (size_t)grid.x * grid.y;
+        (void)hipMalloc(&g_gemm_trace, nblk * 32); (void)hipMemsetAsync(g_gemm_trace, 0, nblk * 32, c->stream);
+    }
     hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
-                       v_col0, vt_sp, sn, sm);
+                       v_col0, vt_sp, sn, sm, g_gemm_trace);
+    if (want_trace) {
+        const size_t nblk = (size_t)grid.x * grid.y;
+        std::vector<unsigned long long> h(nblk * 4);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(h.data(), g_gemm_trace, nblk * 32, hipMemcpyDeviceToHost);
+        double a = 0, b = 0, e = 0; size_t n = 0; unsigned long long lo = ~0ull, hi = 0;
+        for (size_t i = 0; i < nblk; i++) {
+            if (!h[4 * i + 3]) continue;
+            a += (double)(h[4 * i + 1] - h[4 * i]); b += (double)(h[4 * i + 2] - h[4 * i + 1]); e += (double)(h[4 * i + 3] - h[4 * i + 2]); n++;
+            if (h[4 * i] < lo) lo = h[4 * i];
+            if (h[4 * i + 3] > hi) hi = h[4 * i + 3];
+        }
+        if (n) fprintf(stderr, "gemm EPI %d M %d N %d K %d: %zu tiles, ticks/tile: k-loop %.0f, acc->lds %.0f, store %.0f; span %llu ticks\n", EPI, M, N, K, n,
+                       a / n, b / n, e / n, hi - lo);
+        (void)hipFree(g_gemm_trace); g_gemm_trace = nullptr;
+    }
 }
 
 } // namespace
