@@ -13,7 +13,7 @@ int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-KernelTimer::KernelTimer(pce_ctx *ctx, int kid) : c(ctx), id(kid)
+KernelTimer::KernelTimer(pce_ctx *ctx, int kid, hipStream_t on) : c(ctx), id(kid), s(on ? on : ctx->stream)
 {
     if (!c->prof) return;
     auto take = [&]() -> hipEvent_t {
@@ -23,14 +23,23 @@ KernelTimer::KernelTimer(pce_ctx *ctx, int kid) : c(ctx), id(kid)
         return e;
     };
     a = take(); b = take();
-    if (a) (void)hipEventRecord(a, c->stream);
+    if (a) (void)hipEventRecord(a, s);
 }
 KernelTimer::~KernelTimer()
 {
     if (!c->prof || !a || !b) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, s);
     c->pending.push_back({id, a, b});
 }
+int pce_join_aux(pce_ctx *c)
+{
+    if (c->aux_pending) {
+        PCE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->aux_pending = false;
+    }
+    return PCE_OK;
+}
+
 void pce_profile_collect(pce_ctx *ctx, bool wait)
 {
     size_t kept = 0;
@@ -79,6 +88,8 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         c->own_stream = true;
     }
+    if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
+    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
     return c;
 }
 
@@ -86,9 +97,14 @@ void pce_destroy(pce_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)pce_join_aux(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     pce_profile_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     DevBuf *bufs[] = {&c->pcm_own, &c->d_clip_off, &c->en_work, &c->en_out,
                       &c->lu_meta, &c->lu_chunks, &c->lu_blocks, &c->lu_pow, &c->lu_state_end, &c->lu_state_init,
                       &c->lu_energy, &c->lu_zbuf, &c->lu_out, &c->lu_en_work, &c->lu_en_acc,
@@ -110,6 +126,7 @@ const char *pce_last_error(const pce_ctx *c) { return c ? c->err.c_str() : "null
 int pce_sync(pce_ctx *c)
 {
     if (!c) return PCE_E_INVALID;
+    { int rc = pce_join_aux(c); if (rc) return rc; }
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
     return PCE_OK;
@@ -119,6 +136,7 @@ int pce_stats_enqueue(pce_ctx *c, int32_t slot)
 {
     if (!c || slot < 0 || slot > 1) return PCE_E_INVALID;
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_join_aux(c); if (rc) return rc; }           // the pitch summaries come from the auxiliary stream
     pce_ctx::StatSlot &st = c->stat[slot];
     const size_t b_en = pce_energy_stage_bytes(c), b_lu = c->lu_n > 0 ? sizeof(double) * (size_t)c->lu_n : 0, b_pi = pce_pitch_stage_bytes(c);
     auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };

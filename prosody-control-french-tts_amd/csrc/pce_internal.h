@@ -41,6 +41,11 @@ struct pce_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // auxiliary stream: the latency-bound tail of the pitch analysis (path finder + median, ~0.4 ms with few CUs busy)
+    // runs here so that the next launches on `stream` (STFT, the next batch's energy / LUFS) overlap it
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool aux_pending = false;
     std::string err;
     int cu_count = 0;
 
@@ -120,11 +125,12 @@ int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...);
 
 // Kernel-launch bracket for the profiler: records events around the launch when enabled.
 struct KernelTimer {
-    pce_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
-    KernelTimer(pce_ctx *ctx, int kid);
+    pce_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; hipStream_t s;
+    KernelTimer(pce_ctx *ctx, int kid, hipStream_t on = nullptr);
     ~KernelTimer();
 };
-void pce_profile_collect(pce_ctx *ctx, bool wait = true);   // wait = false: only the launches that have completed
+void pce_profile_collect(pce_ctx *ctx, bool wait = true);
+int pce_join_aux(pce_ctx *c);                                // make `stream` wait for the auxiliary stream's pending work   // wait = false: only the launches that have completed
 
 // staged fetch helpers of the modules (pce_stats_*): bytes needed, enqueue the copy into pinned memory, unpack it
 size_t pce_energy_stage_bytes(const pce_ctx *c);

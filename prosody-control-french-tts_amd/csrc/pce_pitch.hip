@@ -1290,6 +1290,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
     if (!c || !p || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_join_aux(c); if (rc) return rc; }           // the previous run's tail still owns the pitch buffers
+    static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
     if (!(c->pi_cache.same(slices, n) && c->pi_params_valid && same_params(c->pi_params, *p))) {
         c->pi_n = -1; c->pi_params_valid = false;
         PitchPlan pl;
@@ -1405,6 +1407,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         c->pi_params = *p; c->pi_params_valid = true;
     }
     PiParams P; memcpy(&P, c->pi_P, sizeof P);
+    hipStream_t tail = c->stream;
     const int64_t total = c->pi_total_frames;
     if (total > 0) {
         int rc = pce_energy_launch(c, n, 500, c->pi_n_energy_work, c->pi_peakwork, c->pi_acc);
@@ -1474,9 +1477,16 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                                    c->pi_dl.as<double2>(), c->pi_f0.as<double>(), c->pi_strength.as<double>(), runs, run_count, run_cap);
             }
             {
-                KernelTimer t(c, PCE_K_PITCH_PATH);
+                // the tail (path finder, median) is latency bound: it goes to the auxiliary stream, so whatever the
+                // caller launches next on the main stream runs beside it; every consumer joins first (pce_join_aux)
+                if (!no_aux) {
+                    PCE_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+                    PCE_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+                    tail = c->aux;
+                }
+                KernelTimer t(c, PCE_K_PITCH_PATH, tail);
                 const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 16u;     // multiple of RUN_LISTS
-                hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, c->stream, P,
+                hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, tail, P,
                                    c->pi_cand.as<double>(), ncand, c->pi_dl.as<double2>(), runs, run_count, run_cap,
                                    c->pi_psi.as<unsigned char>(), c->pi_f0.as<double>(), c->pi_strength.as<double>());
             }
@@ -1486,9 +1496,13 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         const size_t lds = sizeof(double) * (size_t)c->pi_np2;
         if (lds > 64 * 1024)
             PCE_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pitch_median), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        KernelTimer t(c, PCE_K_PITCH_MEDIAN);
-        hipLaunchKernelGGL(k_pitch_median, dim3((unsigned)n), dim3(256), lds, c->stream, c->pi_meta.as<PiSlice>(),
+        KernelTimer t(c, PCE_K_PITCH_MEDIAN, tail);
+        hipLaunchKernelGGL(k_pitch_median, dim3((unsigned)n), dim3(256), lds, tail, c->pi_meta.as<PiSlice>(),
                            c->pi_f0.as<double>(), c->pi_np2, c->pi_summary.as<PiSummaryDev>());
+    }
+    if (tail != c->stream) {
+        PCE_HIP(c, hipEventRecord(c->ev_join, tail));
+        c->aux_pending = true;
     }
     PCE_HIP(c, hipGetLastError());
     c->pi_n = n;
@@ -1500,6 +1514,7 @@ int pce_pitch_fetch(pce_ctx *c, double *f0, double *strength, pce_pitch_summary 
     if (!c) return PCE_E_INVALID;
     if (c->pi_n < 0) return pce_fail(c, PCE_E_STATE, "pce_pitch_fetch before pce_pitch_run");
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_join_aux(c); if (rc) return rc; }
     const int32_t n = c->pi_n;
     const int64_t total = c->pi_total_frames;
     std::vector<PiSummaryDev> sd((size_t)(n > 0 ? n : 1));
