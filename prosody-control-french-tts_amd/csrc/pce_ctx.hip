@@ -31,13 +31,26 @@ KernelTimer::~KernelTimer()
     (void)hipEventRecord(b, s);
     c->pending.push_back({id, a, b});
 }
-int pce_join_aux(pce_ctx *c)
+int pce_join_tail(pce_ctx *c)
 {
     if (c->aux_pending) {
         PCE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         c->aux_pending = false;
     }
     return PCE_OK;
+}
+int pce_join_lufs(pce_ctx *c)
+{
+    if (c->aux2_pending) {
+        PCE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+        c->aux2_pending = false;
+    }
+    return PCE_OK;
+}
+int pce_join_aux(pce_ctx *c)
+{
+    int rc = pce_join_tail(c);
+    return rc ? rc : pce_join_lufs(c);
 }
 
 void pce_profile_collect(pce_ctx *ctx, bool wait)
@@ -88,8 +101,9 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         c->own_stream = true;
     }
-    if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
-    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
+    if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
+    for (hipEvent_t *ev : {&c->ev_fork, &c->ev_join, &c->ev_fork2, &c->ev_join2})
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
     return c;
 }
 
@@ -100,11 +114,15 @@ void pce_destroy(pce_ctx *c)
     (void)pce_join_aux(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
+    if (c->aux2) (void)hipStreamSynchronize(c->aux2);
     pce_profile_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
     DevBuf *bufs[] = {&c->pcm_own, &c->d_clip_off, &c->en_work, &c->en_out,
                       &c->lu_meta, &c->lu_chunks, &c->lu_blocks, &c->lu_pow, &c->lu_state_end, &c->lu_state_init,
                       &c->lu_energy, &c->lu_zbuf, &c->lu_out, &c->lu_en_work, &c->lu_en_acc,
@@ -220,6 +238,7 @@ int pce_upload_pcm_s16(pce_ctx *c, const int16_t *pcm, const int64_t *offsets, i
 {
     if (!c || !pcm) return PCE_E_INVALID;
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_join_aux(c); if (rc) return rc; }           // side-stream kernels may still read the old batch
     int st = set_offsets(c, offsets, n_clips, rate);
     if (st) return st;
     size_t total = (size_t)offsets[n_clips];
@@ -237,6 +256,7 @@ int pce_bind_pcm_s16_device(pce_ctx *c, const void *d_pcm, const int64_t *offset
     if (!c || !d_pcm) return PCE_E_INVALID;
     if (((uintptr_t)d_pcm) & 15) return pce_fail(c, PCE_E_INVALID, "device PCM pointer must be 16-byte aligned");
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_join_aux(c); if (rc) return rc; }
     int st = set_offsets(c, offsets, n_clips, rate);
     if (st) return st;
     c->d_pcm = (const int16_t *)d_pcm;

@@ -139,12 +139,13 @@ int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work
 }
 
 // Launch (async): zero the accumulators, stream the chunks.
-int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf)
+int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf, hipStream_t on)
 {
-    PCE_HIP(c, hipMemsetAsync(out_buf.p, 0, sizeof(EnAcc) * (size_t)(n > 0 ? n : 1), c->stream));
+    const hipStream_t st = on ? on : c->stream;
+    PCE_HIP(c, hipMemsetAsync(out_buf.p, 0, sizeof(EnAcc) * (size_t)(n > 0 ? n : 1), st));
     if (n_work > 0) {
-        KernelTimer t(c, PCE_K_ENERGY);
-        hipLaunchKernelGGL(k_energy, dim3((unsigned)n_work), dim3(EN_THREADS), 0, c->stream,
+        KernelTimer t(c, PCE_K_ENERGY, st);
+        hipLaunchKernelGGL(k_energy, dim3((unsigned)n_work), dim3(EN_THREADS), 0, st,
                            c->d_pcm, work_buf.as<EnWork>(), (int)loud_thr, out_buf.as<EnAcc>());
         PCE_HIP(c, hipGetLastError());
     }
@@ -180,7 +181,7 @@ int pce_energy_run(pce_ctx *c, const pce_slice *slices, int32_t n, int32_t loud_
         if (st) return st;
         c->en_cache.store(slices, n);
     }
-    int st = pce_energy_launch(c, n, loud_thr, c->en_n_work, c->en_work, c->en_out);
+    int st = pce_energy_launch(c, n, loud_thr, c->en_n_work, c->en_work, c->en_out, nullptr);
     if (st) return st;
     c->en_n = n;
     return PCE_OK;

@@ -46,6 +46,10 @@ struct pce_ctx {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool aux_pending = false;
+    // second side stream: the LUFS chain (sequential IIR per lane: latency bound, few waves) runs beside the pitch kernels
+    hipStream_t aux2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    bool aux2_pending = false;
     std::string err;
     int cu_count = 0;
 
@@ -130,7 +134,9 @@ struct KernelTimer {
     ~KernelTimer();
 };
 void pce_profile_collect(pce_ctx *ctx, bool wait = true);
-int pce_join_aux(pce_ctx *c);                                // make `stream` wait for the auxiliary stream's pending work   // wait = false: only the launches that have completed
+int pce_join_aux(pce_ctx *c);                                // make `stream` wait for ALL side-stream work (pitch tail and LUFS)
+int pce_join_tail(pce_ctx *c);                               // ... for the pitch tail only
+int pce_join_lufs(pce_ctx *c);                               // ... for the LUFS chain only   // wait = false: only the launches that have completed
 
 // staged fetch helpers of the modules (pce_stats_*): bytes needed, enqueue the copy into pinned memory, unpack it
 size_t pce_energy_stage_bytes(const pce_ctx *c);

@@ -23,7 +23,7 @@
 #include <cmath>
 
 int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work_buf, DevBuf &out_buf, int64_t *n_work);
-int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf);
+int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf, hipStream_t on = nullptr);
 const int *pce_energy_peak_ptr(const DevBuf &out_buf, size_t *stride_bytes);
 
 namespace {
@@ -371,13 +371,23 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
     if (!c || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
     PCE_HIP(c, hipSetDevice(c->device));
+    static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
     if (!c->lu_cache.same(slices, n)) {
+        { int rc = pce_join_lufs(c); if (rc) return rc; }      // the previous chain still uses the plan's buffers
         c->lu_n = -1;
         int st = lufs_plan(c, slices, n);
         if (st) return st;
         c->lu_cache.store(slices, n);
     }
-    int st = pce_energy_launch(c, n, 500, c->lu_n_energy_work, c->lu_en_work, c->lu_en_acc);
+    // The whole chain goes to the second side stream (forked behind whatever the main stream holds: the upload, the
+    // previous batch's result copies), so the pitch kernels launched next run beside it; consumers join first.
+    hipStream_t ls = c->stream;
+    if (!no_aux) {
+        PCE_HIP(c, hipEventRecord(c->ev_fork2, c->stream));
+        PCE_HIP(c, hipStreamWaitEvent(c->aux2, c->ev_fork2, 0));
+        ls = c->aux2;
+    }
+    int st = pce_energy_launch(c, n, 500, c->lu_n_energy_work, c->lu_en_work, c->lu_en_acc, ls);
     if (st) return st;
     LuCoef k; memcpy(&k, c->lu_coef, sizeof k);
     size_t pstride = 0;
@@ -385,31 +395,35 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
     const int nch = (int)c->lu_n_chunks;
     if (nch > 0) {
         {
-            KernelTimer t(c, PCE_K_LUFS_PASS1);
-            hipLaunchKernelGGL(k_lufs_pass1, dim3((unsigned)div_up(nch, 64)), dim3(64), 0, c->stream, c->d_pcm,
+            KernelTimer t(c, PCE_K_LUFS_PASS1, ls);
+            hipLaunchKernelGGL(k_lufs_pass1, dim3((unsigned)div_up(nch, 64)), dim3(64), 0, ls, c->d_pcm,
                                c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), nch, k, peaks, pstride,
                                c->lu_state_end.as<double>(), (int64_t)c->clip_off[(size_t)c->n_clips]);
         }
         {
-            KernelTimer t(c, PCE_K_LUFS_SCAN);
-            hipLaunchKernelGGL(k_lufs_scan, dim3((unsigned)n), dim3(64), 0, c->stream,
+            KernelTimer t(c, PCE_K_LUFS_SCAN, ls);
+            hipLaunchKernelGGL(k_lufs_scan, dim3((unsigned)n), dim3(64), 0, ls,
                                c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), (int)n, c->lu_pow.as<double>(),
                                c->lu_state_end.as<double>(), c->lu_state_init.as<double>());
         }
         {
-            KernelTimer t(c, PCE_K_LUFS_PASS2);
-            hipLaunchKernelGGL(k_lufs_pass2, dim3((unsigned)div_up(nch, 64)), dim3(64), 0, c->stream, c->d_pcm,
+            KernelTimer t(c, PCE_K_LUFS_PASS2, ls);
+            hipLaunchKernelGGL(k_lufs_pass2, dim3((unsigned)div_up(nch, 64)), dim3(64), 0, ls, c->d_pcm,
                                c->lu_meta.as<LuSlice>(), c->lu_chunks.as<LuChunk>(), nch, k, peaks, pstride,
                                c->lu_state_init.as<double>(), c->lu_energy.as<double>(), (int64_t)c->clip_off[(size_t)c->n_clips]);
         }
     }
     if (n > 0) {
-        KernelTimer t(c, PCE_K_LUFS_GATE);
-        hipLaunchKernelGGL(k_lufs_gate, dim3((unsigned)n), dim3(64), 0, c->stream,
+        KernelTimer t(c, PCE_K_LUFS_GATE, ls);
+        hipLaunchKernelGGL(k_lufs_gate, dim3((unsigned)n), dim3(64), 0, ls,
                            c->lu_meta.as<LuSlice>(), c->lu_blocks.as<LuBlock>(), (int)n, k, c->lu_energy.as<double>(),
                            c->lu_zbuf.as<double>(), c->lu_out.as<double>());
     }
     PCE_HIP(c, hipGetLastError());
+    if (ls != c->stream) {
+        PCE_HIP(c, hipEventRecord(c->ev_join2, ls));
+        c->aux2_pending = true;
+    }
     c->lu_n = n;
     return PCE_OK;
 }
@@ -419,6 +433,7 @@ int pce_lufs_fetch(pce_ctx *c, double *lufs, int32_t *status)
     if (!c || !lufs) return PCE_E_INVALID;
     if (c->lu_n < 0) return pce_fail(c, PCE_E_STATE, "pce_lufs_fetch before pce_lufs_run");
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_join_lufs(c); if (rc) return rc; }
     if (c->lu_n > 0)
         PCE_HIP(c, hipMemcpyAsync(lufs, c->lu_out.p, sizeof(double) * (size_t)c->lu_n, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));

@@ -30,7 +30,7 @@
 #include <cstdlib>
 
 int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work_buf, DevBuf &out_buf, int64_t *n_work);
-int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf);
+int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, DevBuf &work_buf, DevBuf &out_buf, hipStream_t on = nullptr);
 void pce_energy_range_ptrs(const DevBuf &out_buf, size_t *stride_bytes, const long long **sum, const int **m_hi, const int **m_lo);
 
 // ---------------------------------------------------------------------------
@@ -1290,7 +1290,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
     if (!c || !p || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_join_aux(c); if (rc) return rc; }           // the previous run's tail still owns the pitch buffers
+    { int rc = pce_join_tail(c); if (rc) return rc; }          // the previous run's tail still owns the pitch buffers
     static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
     if (!(c->pi_cache.same(slices, n) && c->pi_params_valid && same_params(c->pi_params, *p))) {
         c->pi_n = -1; c->pi_params_valid = false;
@@ -1514,7 +1514,7 @@ int pce_pitch_fetch(pce_ctx *c, double *f0, double *strength, pce_pitch_summary 
     if (!c) return PCE_E_INVALID;
     if (c->pi_n < 0) return pce_fail(c, PCE_E_STATE, "pce_pitch_fetch before pce_pitch_run");
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_join_aux(c); if (rc) return rc; }
+    { int rc = pce_join_tail(c); if (rc) return rc; }
     const int32_t n = c->pi_n;
     const int64_t total = c->pi_total_frames;
     std::vector<PiSummaryDev> sd((size_t)(n > 0 ? n : 1));
