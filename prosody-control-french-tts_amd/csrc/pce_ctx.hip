@@ -1,5 +1,6 @@
 // pce_ctx.hip -- context, batch residency, profiling brackets of libpce.so.
 #include "pce_internal.h"
+#include <cstdlib>
 #include <cstring>
 #include <cstdarg>
 
@@ -31,26 +32,38 @@ KernelTimer::~KernelTimer()
     (void)hipEventRecord(b, s);
     c->pending.push_back({id, a, b});
 }
-int pce_join_tail(pce_ctx *c)
+int pce_side_join(pce_ctx *c, int which)
 {
-    if (c->aux_pending) {
-        PCE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        c->aux_pending = false;
-    }
-    return PCE_OK;
-}
-int pce_join_lufs(pce_ctx *c)
-{
-    if (c->aux2_pending) {
-        PCE_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
-        c->aux2_pending = false;
+    pce_ctx::Side &sd = c->side[which];
+    if (sd.pending) {
+        PCE_HIP(c, hipStreamWaitEvent(c->stream, sd.join, 0));
+        sd.pending = false;
     }
     return PCE_OK;
 }
 int pce_join_aux(pce_ctx *c)
 {
-    int rc = pce_join_tail(c);
-    return rc ? rc : pce_join_lufs(c);
+    for (int i = 0; i < pce_ctx::SIDE_COUNT; i++) { int rc = pce_side_join(c, i); if (rc) return rc; }
+    return PCE_OK;
+}
+int pce_side_begin(pce_ctx *c, int which, hipStream_t *out)
+{
+    static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
+    *out = c->stream;
+    if (no_aux) return PCE_OK;
+    pce_ctx::Side &sd = c->side[which];
+    PCE_HIP(c, hipEventRecord(sd.fork, c->stream));
+    PCE_HIP(c, hipStreamWaitEvent(sd.s, sd.fork, 0));
+    *out = sd.s;
+    return PCE_OK;
+}
+int pce_side_end(pce_ctx *c, int which, hipStream_t used)
+{
+    if (used == c->stream) return PCE_OK;
+    pce_ctx::Side &sd = c->side[which];
+    PCE_HIP(c, hipEventRecord(sd.join, used));
+    sd.pending = true;
+    return PCE_OK;
 }
 
 void pce_profile_collect(pce_ctx *ctx, bool wait)
@@ -101,9 +114,10 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         c->own_stream = true;
     }
-    if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
-    for (hipEvent_t *ev : {&c->ev_fork, &c->ev_join, &c->ev_fork2, &c->ev_join2})
-        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
+    for (auto &sd : c->side) {
+        if ((e = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
+        if ((e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
+    }
     return c;
 }
 
@@ -113,16 +127,14 @@ void pce_destroy(pce_ctx *c)
     (void)hipSetDevice(c->device);
     (void)pce_join_aux(c);
     (void)hipStreamSynchronize(c->stream);
-    if (c->aux) (void)hipStreamSynchronize(c->aux);
-    if (c->aux2) (void)hipStreamSynchronize(c->aux2);
+    for (auto &sd : c->side) if (sd.s) (void)hipStreamSynchronize(sd.s);
     pce_profile_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
-    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
-    if (c->aux2) (void)hipStreamDestroy(c->aux2);
+    for (auto &sd : c->side) {
+        if (sd.fork) (void)hipEventDestroy(sd.fork);
+        if (sd.join) (void)hipEventDestroy(sd.join);
+        if (sd.s) (void)hipStreamDestroy(sd.s);
+    }
     DevBuf *bufs[] = {&c->pcm_own, &c->d_clip_off, &c->en_work, &c->en_out,
                       &c->lu_meta, &c->lu_chunks, &c->lu_blocks, &c->lu_pow, &c->lu_state_end, &c->lu_state_init,
                       &c->lu_energy, &c->lu_zbuf, &c->lu_out, &c->lu_en_work, &c->lu_en_acc,

@@ -41,15 +41,14 @@ struct pce_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // auxiliary stream: the latency-bound tail of the pitch analysis (path finder + median, ~0.4 ms with few CUs busy)
-    // runs here so that the next launches on `stream` (STFT, the next batch's energy / LUFS) overlap it
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool aux_pending = false;
-    // second side stream: the LUFS chain (sequential IIR per lane: latency bound, few waves) runs beside the pitch kernels
-    hipStream_t aux2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
-    bool aux2_pending = false;
+    // side streams: work that leaves most of the machine idle (or is independent of what the caller launches next) is
+    // forked from `stream` onto one of these and joined back by whoever consumes its results:
+    //   SIDE_TAIL  path finder + median of the pitch analysis (latency bound, ~0.4 ms with few CUs busy)
+    //   SIDE_LUFS  the LUFS chain (sequential IIR per lane: few waves, long dependent chains)
+    // (the STFT passes were tried on a third one, launched beside the pitch kernels: both are VALU bound and the step
+    //  got slower, 3.33 -> 3.54 ms; they stay on `stream`, where they overlap the pitch tail)
+    enum { SIDE_TAIL = 0, SIDE_LUFS = 1, SIDE_COUNT = 2 };
+    struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; } side[SIDE_COUNT];
     std::string err;
     int cu_count = 0;
 
@@ -134,9 +133,10 @@ struct KernelTimer {
     ~KernelTimer();
 };
 void pce_profile_collect(pce_ctx *ctx, bool wait = true);
-int pce_join_aux(pce_ctx *c);                                // make `stream` wait for ALL side-stream work (pitch tail and LUFS)
-int pce_join_tail(pce_ctx *c);                               // ... for the pitch tail only
-int pce_join_lufs(pce_ctx *c);                               // ... for the LUFS chain only   // wait = false: only the launches that have completed
+int pce_join_aux(pce_ctx *c);                                // make `stream` wait for ALL pending side-stream work
+int pce_side_join(pce_ctx *c, int which);                    // ... for one side stream
+int pce_side_begin(pce_ctx *c, int which, hipStream_t *out); // fork: *out = side stream ordered behind `stream` (or `stream` itself: PCE_NO_AUX)
+int pce_side_end(pce_ctx *c, int which, hipStream_t used);   // record the join point   // wait = false: only the launches that have completed
 
 // staged fetch helpers of the modules (pce_stats_*): bytes needed, enqueue the copy into pinned memory, unpack it
 size_t pce_energy_stage_bytes(const pce_ctx *c);

@@ -371,9 +371,8 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
     if (!c || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
     PCE_HIP(c, hipSetDevice(c->device));
-    static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
     if (!c->lu_cache.same(slices, n)) {
-        { int rc = pce_join_lufs(c); if (rc) return rc; }      // the previous chain still uses the plan's buffers
+        { int rc = pce_side_join(c, pce_ctx::SIDE_LUFS); if (rc) return rc; }      // the previous chain still uses the plan's buffers
         c->lu_n = -1;
         int st = lufs_plan(c, slices, n);
         if (st) return st;
@@ -382,11 +381,7 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
     // The whole chain goes to the second side stream (forked behind whatever the main stream holds: the upload, the
     // previous batch's result copies), so the pitch kernels launched next run beside it; consumers join first.
     hipStream_t ls = c->stream;
-    if (!no_aux) {
-        PCE_HIP(c, hipEventRecord(c->ev_fork2, c->stream));
-        PCE_HIP(c, hipStreamWaitEvent(c->aux2, c->ev_fork2, 0));
-        ls = c->aux2;
-    }
+    { int rc = pce_side_begin(c, pce_ctx::SIDE_LUFS, &ls); if (rc) return rc; }
     int st = pce_energy_launch(c, n, 500, c->lu_n_energy_work, c->lu_en_work, c->lu_en_acc, ls);
     if (st) return st;
     LuCoef k; memcpy(&k, c->lu_coef, sizeof k);
@@ -420,10 +415,7 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
                            c->lu_zbuf.as<double>(), c->lu_out.as<double>());
     }
     PCE_HIP(c, hipGetLastError());
-    if (ls != c->stream) {
-        PCE_HIP(c, hipEventRecord(c->ev_join2, ls));
-        c->aux2_pending = true;
-    }
+    { int rc = pce_side_end(c, pce_ctx::SIDE_LUFS, ls); if (rc) return rc; }
     c->lu_n = n;
     return PCE_OK;
 }
@@ -433,7 +425,7 @@ int pce_lufs_fetch(pce_ctx *c, double *lufs, int32_t *status)
     if (!c || !lufs) return PCE_E_INVALID;
     if (c->lu_n < 0) return pce_fail(c, PCE_E_STATE, "pce_lufs_fetch before pce_lufs_run");
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_join_lufs(c); if (rc) return rc; }
+    { int rc = pce_side_join(c, pce_ctx::SIDE_LUFS); if (rc) return rc; }
     if (c->lu_n > 0)
         PCE_HIP(c, hipMemcpyAsync(lufs, c->lu_out.p, sizeof(double) * (size_t)c->lu_n, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));

@@ -1290,8 +1290,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
     if (!c || !p || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_join_tail(c); if (rc) return rc; }          // the previous run's tail still owns the pitch buffers
-    static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
+    { int rc = pce_side_join(c, pce_ctx::SIDE_TAIL); if (rc) return rc; }   // the previous run's tail still owns the pitch buffers
     if (!(c->pi_cache.same(slices, n) && c->pi_params_valid && same_params(c->pi_params, *p))) {
         c->pi_n = -1; c->pi_params_valid = false;
         PitchPlan pl;
@@ -1479,11 +1478,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             {
                 // the tail (path finder, median) is latency bound: it goes to the auxiliary stream, so whatever the
                 // caller launches next on the main stream runs beside it; every consumer joins first (pce_join_aux)
-                if (!no_aux) {
-                    PCE_HIP(c, hipEventRecord(c->ev_fork, c->stream));
-                    PCE_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-                    tail = c->aux;
-                }
+                { int rc2 = pce_side_begin(c, pce_ctx::SIDE_TAIL, &tail); if (rc2) return rc2; }
                 KernelTimer t(c, PCE_K_PITCH_PATH, tail);
                 const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 16u;     // multiple of RUN_LISTS
                 hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, tail, P,
@@ -1500,10 +1495,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         hipLaunchKernelGGL(k_pitch_median, dim3((unsigned)n), dim3(256), lds, tail, c->pi_meta.as<PiSlice>(),
                            c->pi_f0.as<double>(), c->pi_np2, c->pi_summary.as<PiSummaryDev>());
     }
-    if (tail != c->stream) {
-        PCE_HIP(c, hipEventRecord(c->ev_join, tail));
-        c->aux_pending = true;
-    }
+    { int rc2 = pce_side_end(c, pce_ctx::SIDE_TAIL, tail); if (rc2) return rc2; }
     PCE_HIP(c, hipGetLastError());
     c->pi_n = n;
     return PCE_OK;
@@ -1514,7 +1506,7 @@ int pce_pitch_fetch(pce_ctx *c, double *f0, double *strength, pce_pitch_summary 
     if (!c) return PCE_E_INVALID;
     if (c->pi_n < 0) return pce_fail(c, PCE_E_STATE, "pce_pitch_fetch before pce_pitch_run");
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_join_tail(c); if (rc) return rc; }
+    { int rc = pce_side_join(c, pce_ctx::SIDE_TAIL); if (rc) return rc; }
     const int32_t n = c->pi_n;
     const int64_t total = c->pi_total_frames;
     std::vector<PiSummaryDev> sd((size_t)(n > 0 ? n : 1));
