@@ -756,7 +756,8 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[144 / G], in
     const double dlim = (double)D;
     const int left = midright - D, right = midleft + D;
     const double a_l = PI_D * (x - (double)midleft), a_r = PI_D * ((double)midright - x);
-    const double hs = 0.5 * sin_0pi(a_l);
+    // sin(pi f) = sin(pi (1 - f)): fold to [0, pi/2] and take ONE polynomial (sin_0pi costs a sine and a cosine)
+    const double hs = 0.5 * sin_q(fmin(a_l, a_r));
     const double rden_l = rcp_f64(x - (double)left + 1.0), rden_r = rcp_f64((double)right - x + 1.0);
     const double aa_l = a_l * rden_l, daa_l = PI_D * rden_l;
     const double aa_r = a_r * rden_r, daa_r = PI_D * rden_r;
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
                         q = 2.0 * (q - tt);
                         if (q > 0.0) p = -p; else q = -q;
                         if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
-                            new_step = p / q;
+                            new_step = p * rcp_f64(q);          // (an IEEE divide is ~35 instructions; this is within 1 ulp of it)
                     }
                     if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
                     t = x + new_step;
