@@ -775,38 +775,53 @@ __device__ __forceinline__ double sinc_group_reg(const double (&yv)[144 / G], in
         const double ts = (is_left ? hs_l : hs_r) * sinc_w(kd, is_left ? a_l : a_r, yv[RS] * u);
         acc = (kd >= 0.0 && kd < dlim) ? ts : 0.0;
     }
+    // Two rows share one reciprocal: t0/a0 + t1/a1 = (t0 a1 + t1 a0) / (a0 a1) (a = pi (k + frac) > 0; a v_rcp_f64
+    // issues at quarter rate), so the rows are first collected (masked numerators t = y (1 + cos), denominators a)
+    // and then folded in pairs.
     {   // left side, rows RS-1 (nearest x) .. 0
+        constexpr int NL = RS;
+        double tv[NL], av[NL];
         const double cq = cos_q(0.5 * G * daa_l);                       // cos(delta / 2), delta = G daa <= pi
         const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
         const double k1 = kdl - (double)(G * (RS - 1)), k0 = kdl - (double)(G * (RS - 2));
         double u1 = one_plus_cos_0pi(fma(k1, daa_l, aa_l));
         double u0 = one_plus_cos_0pi(fma(k0, daa_l, aa_l));
-        double side = keep(k1, sinc_w(k1, a_l, yv[RS - 1] * u1));
-        side += keep(k0, sinc_w(k0, a_l, yv[RS - 2] * u0));
+        tv[0] = keep(k1, yv[RS - 1] * u1); av[0] = fma(k1, PI_D, a_l);
+        tv[1] = keep(k0, yv[RS - 2] * u0); av[1] = fma(k0, PI_D, a_l);
 #pragma unroll
         for (int m = RS - 3; m >= 0; m--) {
             const double u = fma(tc, u0, g - u1);        // (g - u1) is off the critical path
             u1 = u0; u0 = u;
             const double kd = kdl - (double)(G * m);
-            side += keep(kd, sinc_w(kd, a_l, yv[m] * u));
+            tv[RS - 1 - m] = keep(kd, yv[m] * u); av[RS - 1 - m] = fma(kd, PI_D, a_l);
         }
+        double side = 0.0;
+#pragma unroll
+        for (int q = 0; q + 1 < NL; q += 2) side += fma(tv[q], av[q + 1], tv[q + 1] * av[q]) * rcp_f64(av[q] * av[q + 1]);
+        if (NL & 1) side += tv[NL - 1] * rcp_f64(av[NL - 1]);
         acc = fma(hs_l, side, acc);
     }
     {   // right side, rows RS+1 (nearest x) .. NR-1
+        constexpr int NRt = NR - RS - 1;
+        double tv[NRt], av[NRt];
         const double cq = cos_q(0.5 * G * daa_r);
         const double tc = fma(4.0 * cq, cq, -2.0), g = 2.0 - tc;
         const double k1 = kdr + (double)(G * (RS + 1)), k0 = kdr + (double)(G * (RS + 2));
         double u1 = one_plus_cos_0pi(fma(k1, daa_r, aa_r));
         double u0 = one_plus_cos_0pi(fma(k0, daa_r, aa_r));
-        double side = keep(k1, sinc_w(k1, a_r, yv[RS + 1] * u1));
-        side += keep(k0, sinc_w(k0, a_r, yv[RS + 2] * u0));
+        tv[0] = keep(k1, yv[RS + 1] * u1); av[0] = fma(k1, PI_D, a_r);
+        tv[1] = keep(k0, yv[RS + 2] * u0); av[1] = fma(k0, PI_D, a_r);
 #pragma unroll
         for (int m = RS + 3; m < NR; m++) {
             const double u = fma(tc, u0, g - u1);        // (g - u1) is off the critical path
             u1 = u0; u0 = u;
             const double kd = kdr + (double)(G * m);
-            side += keep(kd, sinc_w(kd, a_r, yv[m] * u));
+            tv[m - RS - 1] = keep(kd, yv[m] * u); av[m - RS - 1] = fma(kd, PI_D, a_r);
         }
+        double side = 0.0;
+#pragma unroll
+        for (int q = 0; q + 1 < NRt; q += 2) side += fma(tv[q], av[q + 1], tv[q + 1] * av[q]) * rcp_f64(av[q] * av[q + 1]);
+        if (NRt & 1) side += tv[NRt - 1] * rcp_f64(av[NRt - 1]);
         acc = fma(hs_r, side, acc);
     }
     return group_sum<G>(acc);
