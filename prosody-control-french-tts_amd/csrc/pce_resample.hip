@@ -42,6 +42,7 @@ int pce_resample_run(pce_ctx *c, int32_t up, int32_t down, const double *taps, i
 {
     if (!c || !taps || up <= 0 || down <= 0 || n_taps <= 0 || n_pre_remove < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
+    { int rc = pce_join_aux(c); if (rc) return rc; }           // side-stream kernels may still read the batch this call replaces
     if (((int64_t)c->rate * up) % down) return pce_fail(c, PCE_E_INVALID, "rate %d * %d / %d is not an integer", c->rate, up, down);
     PCE_HIP(c, hipSetDevice(c->device));
     const int32_t n = c->n_clips;
