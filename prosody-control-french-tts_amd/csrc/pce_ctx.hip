@@ -48,9 +48,8 @@ int pce_join_aux(pce_ctx *c)
 }
 int pce_side_begin(pce_ctx *c, int which, hipStream_t *out)
 {
-    static const bool no_aux = getenv("PCE_NO_AUX") != nullptr;
     *out = c->stream;
-    if (no_aux) return PCE_OK;
+    if (c->no_side) return PCE_OK;
     pce_ctx::Side &sd = c->side[which];
     PCE_HIP(c, hipEventRecord(sd.fork, c->stream));
     PCE_HIP(c, hipStreamWaitEvent(sd.s, sd.fork, 0));
@@ -114,6 +113,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         c->own_stream = true;
     }
+    c->no_side = getenv("PCE_NO_AUX") != nullptr;
     for (auto &sd : c->side) {
         if ((e = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         if ((e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }

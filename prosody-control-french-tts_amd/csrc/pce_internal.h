@@ -49,6 +49,7 @@ struct pce_ctx {
     //  got slower, 3.33 -> 3.54 ms; they stay on `stream`, where they overlap the pitch tail)
     enum { SIDE_TAIL = 0, SIDE_LUFS = 1, SIDE_COUNT = 2 };
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; } side[SIDE_COUNT];
+    bool no_side = false;                // PCE_NO_AUX at pce_create: everything on `stream`
     std::string err;
     int cu_count = 0;
 

@@ -171,3 +171,24 @@ def test_nw_align_gpu_reproduces_the_reference_alignments(engine, tmp_path):
             assert NW.format_alignment(g) == NW.format_alignment(NW.needleman_wunsch(a, b))
         else:       # the reference indexes seq[-1] of an empty list (IndexError); the kernel aligns everything to gaps
             assert len(g[0]) == len(a) + len(b) and [w for w in g[0] if w[0] != "-"] == a and [w for w in g[1] if w[0] != "-"] == b
+
+
+@pytest.mark.gpu
+def test_side_streams_do_not_change_results(engine, synth16k, monkeypatch):
+    """The LUFS chain and the pitch tail run on side streams; a context created with PCE_NO_AUX=1 (single stream)
+    must produce bit-identical results, also with a second batch queued behind the first."""
+    clips = synth16k[:4]
+    p = pkg.PitchParams.praat(150.0, 600.0)
+
+    def run(eng):
+        eng.upload(clips, 16000); sl = eng.whole_clip_slices()
+        for _ in range(2):
+            eng.energy_run(sl, 500); eng.lufs_run(sl); eng.pitch_run(sl, p); eng.stft_db_run(1024, 256)
+        r = eng.pitch_fetch(want_f0=True, want_strength=True)
+        return [eng.lufs_fetch()[0].tobytes(), r["f0"].tobytes(), r["strength"].tobytes(), r["summary"].tobytes(), eng.stft_db_fetch(1).tobytes()]
+
+    monkeypatch.setenv("PCE_NO_AUX", "1")
+    with pkg.ProsodyEngine(0) as single:
+        ref = run(single)
+    monkeypatch.delenv("PCE_NO_AUX")
+    assert run(engine) == ref
