@@ -236,7 +236,9 @@ __device__ double2 *fft_wave(double2 *src, double2 *dst, int M, const double2 *_
 // Exchange images: [k0][72] and [c][65] complex: ds_write_b128 (8 contiguous lanes per group,
 // 128-byte bank rows) and ds_read_b128 (16-lane groups, 256-byte rows) are both conflict-free.
 // ---------------------------------------------------------------------------
-constexpr int R_WAVE_F64 = 2 * 8 * 72;              // doubles of LDS per wavefront on the register paths
+constexpr int R_WAVE_F64 = 2 * 8 * 72;              // doubles of LDS per wavefront on the register paths (MODE 1, 2)
+constexpr int R3_WAVE_F64 = 2 * 1168;               // ... MODE 3: images [16][72] and [8][129] (+64) complex
+constexpr int reg_wave_f64(int mode) { return mode == 3 ? R3_WAVE_F64 : R_WAVE_F64; }
 __device__ __forceinline__ void dft8_f64(double2 (&a)[8])
 {
     const double r = 0.70710678118654752440;
@@ -279,6 +281,76 @@ __device__ __forceinline__ void fft512_reg(double2 (&z)[8], double2 *ex, const d
     for (int q = 0; q < 8; q++) z[q] = ex[65 * q + lane];
     wave_sync();
     dft8_f64(z);
+}
+
+// forward DFT of 1024 points (N = 2048: 44.1 kHz at the 150 Hz floor -- the rate of the reference's own recordings)
+// by one wavefront, 16 complex points per lane: 1024 = 16 x 8 x 8.
+//   stage 1: lane l holds x[64 a + l], a < 16         -> DFT16 over a, twiddle W1024^(l k0)
+//   stage 2: lane (c + 8 k0lo) holds y1[k0lo + 8 g][8 b + c]  -> two DFT8 over b, twiddle W64^(c k1)
+//   stage 3: lane (k0 + 16 k1lo) holds y2[k0][k1lo + 4 g][c]  -> two DFT8 over c: X[k0 + 16 k1 + 128 k2]
+// and the result is back in the input layout (index = lane + 64 r, r = g + 2 k2).  Exchange images [k0][72] and
+// [c][129] complex (conflict-free for ds_write_b128 / ds_read_b128 like the 512-point ones).
+__device__ __forceinline__ void dft4_f64(double2 &a0, double2 &a1, double2 &a2, double2 &a3)
+{
+    const double2 t0 = make_double2(a0.x + a2.x, a0.y + a2.y), t1 = make_double2(a0.x - a2.x, a0.y - a2.y);
+    const double2 t2 = make_double2(a1.x + a3.x, a1.y + a3.y), t3 = make_double2(a1.y - a3.y, -(a1.x - a3.x));   // (a1 - a3)(-i)
+    a0 = make_double2(t0.x + t2.x, t0.y + t2.y); a1 = make_double2(t1.x + t3.x, t1.y + t3.y);
+    a2 = make_double2(t0.x - t2.x, t0.y - t2.y); a3 = make_double2(t1.x - t3.x, t1.y - t3.y);
+}
+__device__ __forceinline__ void dft16_f64(double2 (&x)[16])
+{
+    // n = 4 n1 + n2: DFT4 over n1, twiddle W16^(n2 k1), DFT4 over n2 -> X[k1 + 4 k2]
+    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, r = 0.70710678118654752440;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4_f64(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);       // x[4 k1 + n2] = A[n2][k1]
+    auto mulc = [](double2 a, double wr, double wi) { return make_double2(fma(a.x, wr, -(a.y * wi)), fma(a.x, wi, a.y * wr)); };
+    x[4 + 1] = mulc(x[4 + 1], c1, -s1);  x[4 + 2] = mulc(x[4 + 2], r, -r);   x[4 + 3] = mulc(x[4 + 3], s1, -c1);     // W16^1, W16^2, W16^3
+    x[8 + 1] = mulc(x[8 + 1], r, -r);    x[8 + 2] = make_double2(x[8 + 2].y, -x[8 + 2].x);                           // W16^2, W16^4 = -i
+    x[8 + 3] = mulc(x[8 + 3], -r, -r);                                                                             // W16^6
+    x[12 + 1] = mulc(x[12 + 1], s1, -c1); x[12 + 2] = mulc(x[12 + 2], -r, -r); x[12 + 3] = mulc(x[12 + 3], -c1, s1); // W16^3, W16^6, W16^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4_f64(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);   // x[4 k1 + k2] = X[k1 + 4 k2]
+    // to natural order X[k] at x[k]: transpose the 4 x 4 index (k1, k2) -> (k2, k1)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) { const double2 t = x[4 * i + j]; x[4 * i + j] = x[4 * j + i]; x[4 * j + i] = t; }
+}
+__device__ __forceinline__ void fft1024_reg(double2 (&z)[16], double2 *ex, const double2 *tw1 /* [15][64]: W1024^(l k) */,
+                                            const double2 *tw2 /* [7][8]: W64^(c k) */, int lane)
+{
+    dft16_f64(z);
+#pragma unroll
+    for (int k = 1; k < 16; k++) z[k] = cmul_f64(z[k], tw1[(k - 1) * 64 + lane]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) ex[72 * k + lane] = z[k];
+    wave_sync();
+    const int c = lane & 7, k0lo = lane >> 3;
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) z[8 * g + b] = ex[72 * (k0lo + 8 * g) + 8 * b + c];
+    wave_sync();
+    {
+        double2 h0[8], h1[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) { h0[b] = z[b]; h1[b] = z[8 + b]; }
+        dft8_f64(h0); dft8_f64(h1);
+#pragma unroll
+        for (int k = 1; k < 8; k++) { const double2 w = tw2[(k - 1) * 8 + c]; h0[k] = cmul_f64(h0[k], w); h1[k] = cmul_f64(h1[k], w); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ex[129 * c + k0lo + 16 * k] = h0[k]; ex[129 * c + k0lo + 8 + 16 * k] = h1[k]; }
+    }
+    wave_sync();
+    {
+        double2 h0[8], h1[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { h0[q] = ex[129 * q + lane]; h1[q] = ex[129 * q + 64 + lane]; }
+        wave_sync();
+        dft8_f64(h0); dft8_f64(h1);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { z[2 * k2] = h0[k2]; z[2 * k2 + 1] = h1[k2]; }
+    }
 }
 
 // forward DFT of 256 points by a HALF wavefront (two frames per wavefront): 256 = 8 x 8 x 4,
@@ -332,6 +404,7 @@ template <int W> __device__ __forceinline__ double group_max_f64(double v)
 // MODE 1: N = 1024, one frame per wavefront, register-resident transform.
 // MODE 2: N = 512 (16 kHz at the reference's 150 Hz floor, Code/audioPipeline.py:329), TWO frames per
 //         wavefront (one per 32-lane half), register-resident transform.
+// MODE 3: N = 2048 (44.1 kHz at that floor), one frame per wavefront, 16 points per lane.
 template <int WPB, int MODE, bool TABS>
 __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const int16_t *__restrict__ pcm, const PiSlice *__restrict__ slices, const PiWork *__restrict__ work, int n_work,
@@ -345,8 +418,10 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     constexpr int LW = MODE == 2 ? 32 : 64;              // lanes per frame
     constexpr int FPW = 64 / LW;                         // frames per wavefront
     constexpr int FPB = MODE == 2 ? 2 * PI_FPB : PI_FPB; // frames per work item (host: P.fpb)
-    constexpr int MR = 8 * LW;                           // M on the register paths
-    constexpr int REG_C = R_WAVE_F64 / 2 / FPW;          // complex slots per frame on the register paths
+    constexpr int MR = (MODE == 3 ? 16 : 8) * LW;        // M on the register paths
+    constexpr int R = MODE == 3 ? 16 : 8;                // complex points per lane on the register paths
+    constexpr int RW = reg_wave_f64(MODE);               // doubles of LDS per wavefront there
+    constexpr int REG_C = RW / 2 / FPW;                  // complex slots per frame on the register paths
     extern __shared__ double lds[];
     // XCD-aware remap: consecutive work items (overlapping windows of one slice) go to one XCD's L2
     const int nb = (int)gridDim.x;
@@ -358,7 +433,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     if (bid >= n_work) return;
     const PiWork wk = work[bid];
     const PiSlice s = slices[wk.slice];
-    double2 *wave_base = reinterpret_cast<double2 *>(lds) + (MODE == 0 ? (size_t)wv * (size_t)(2 * P.zlen) : (size_t)wv * (R_WAVE_F64 / 2));
+    double2 *wave_base = reinterpret_cast<double2 *>(lds) + (MODE == 0 ? (size_t)wv * (size_t)(2 * P.zlen) : (size_t)wv * (reg_wave_f64(MODE) / 2));
     double2 *bufA = MODE == 0 ? wave_base : wave_base + half * REG_C;
     double2 *bufB = bufA + P.zlen;                      // (MODE 0 only)
     double *xr = reinterpret_cast<double *>(bufA);      // MODE 0: real view of bufA: x[j] at xr[2 ZP(j>>1) + (j&1)]
@@ -369,7 +444,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const int16_t *spcm = nullptr;
     int64_t lo = 0;
     if constexpr (MODE != 0) {
-        double *tab = lds + WPB * R_WAVE_F64;
+        double *tab = lds + WPB * RW;
         if constexpr (TABS) {
             for (int i = (int)threadIdx.x; i < (P.blob_f64 >> 1); i += 64 * WPB)
                 reinterpret_cast<double2 *>(tab)[i] = reinterpret_cast<const double2 *>(blob)[i];
@@ -379,7 +454,10 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
             tw1 = reinterpret_cast<const double2 *>(blob); tw2 = reinterpret_cast<const double2 *>(blob + P.o_tw2);
             twR = reinterpret_cast<const double2 *>(blob + P.o_twN); win = blob + P.o_win; winR = blob + P.o_winR;
         }
-        int16_t *sp = reinterpret_cast<int16_t *>(tab + (TABS ? P.blob_f64 : 0));
+    }
+    {   // every mode: the samples under this work item's frames, staged once per workgroup
+        int16_t *sp = MODE != 0 ? reinterpret_cast<int16_t *>(lds + WPB * RW + (TABS ? P.blob_f64 : 0))
+                                : reinterpret_cast<int16_t *>(lds + (size_t)WPB * 4 * (size_t)P.zlen);
         const double tA = s.t1 + (double)wk.frame0 * P.dt;
         lo = (int64_t)floor((tA - s.x1) / P.dx) + 1 - P.hw;       // window start of the first frame (slice-relative)
         for (int i = (int)threadIdx.x; i < P.pcm_span; i += 64 * WPB) {
@@ -418,13 +496,13 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const int64_t ws = L0 + 1 - P.hw;                             // first sample of the window (slice-relative)
     const int64_t m0 = L0 + 1 - P.nsp, m1 = L0 + P.nsp;           // local-mean range, inclusive
 
-    double2 z[8];                                        // register paths: z[r] = x[2n] + i x[2n+1], n = hl + LW r
+    double2 z[R];                                        // register paths: z[r] = x[2n] + i x[2n+1], n = hl + LW r
     double lpk = 0.0;
     const int pk0 = max(P.hw + 1 - P.hsp, 1), pk1 = min(P.hw + P.hsp, P.nw);   // 1-based inclusive
     if constexpr (MODE != 0) {
-        int isum = 0, v[16];
+        int isum = 0, v[2 * R];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < R; r++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int j = 2 * (hl + LW * r) + h;
@@ -440,7 +518,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
         isum = group_sum_i32<LW>(isum);
         const double localMean = ((double)isum / 32768.0) / (double)(2 * P.nsp);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < R; r++) {
             double f[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -459,8 +537,8 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     for (int j = lane; j < P.nfft; j += 64) {
         int v = 0;
         if (j < P.nw) {
-            const int64_t rel = ws + j, cc = s.begin + rel;
-            if (rel >= 0 && rel < s.nx && cc >= 0 && cc < s.clip_len) v = (int)pcm[s.clip_off + cc];
+            const int64_t rel = ws + j;
+            v = (int)spcm[(int)(ws - lo) + j];
             if (rel >= m0 && rel <= m1) isum += v;
         }
         xr[2 * ZP(j >> 1) + (j & 1)] = (double)v / 32768.0;
@@ -485,15 +563,15 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     if (__ballot(active) != 0) {
         if constexpr (MODE != 0) {
             wave_sync();
-            if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
+            if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else if constexpr (MODE == 3) fft1024_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
             // power spectrum of the real frame, re-tangled for the second transform.  Lane-local form of
             // the pairwise loop of MODE 0: for every own k, with zm = Z[M - k],
             // X[k] = ez + t, X[M - k]* = ez - t, and W[k] = (e - d sin, -d cos) holds for all k in [0, M).
 #pragma unroll
-            for (int r = 0; r < 8; r++) bufA[hl + LW * r] = z[r];
+            for (int r = 0; r < R; r++) bufA[hl + LW * r] = z[r];
             wave_sync();
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < R; r++) {
                 const int k = hl + LW * r;
                 const double2 zk = z[r], zm = bufA[(MR - k) & (MR - 1)];
                 const double2 w = twR[k];                                     // (cos, -sin)
@@ -506,14 +584,14 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
                 z[r] = make_double2(e - d * (-w.y), -(d * w.x));
             }
             wave_sync();
-            if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
+            if constexpr (MODE == 1) fft512_reg(z, bufA, tw1, tw2, lane); else if constexpr (MODE == 3) fft1024_reg(z, bufA, tw1, tw2, lane); else fft256_half(z, bufA, tw1, tw2, hl);
             // ac[2n] = Re Y[n], ac[2n+1] = -Im Y[n]; r[k] = ac[k] / (ac[0] windowR[k]) into the same region
             // (reciprocal to < 1 ulp and a multiply: the quotient is not correctly rounded, like the transforms before it)
             rr = reinterpret_cast<double *>(bufA);
             const double ac0 = __shfl(z[0].x, lane & ~(LW - 1), 64);
             if (active) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
+                for (int r = 0; r < R; r++) {
                     const int k = 2 * (hl + LW * r);
                     if (k >= 1 && k <= P.bix) { const double v = z[r].x * rcp_f64(ac0 * winR[k]); rr[P.bix + k] = v; rr[P.bix - k] = v; }
                     if (k + 1 <= P.bix) { const double v = -z[r].y * rcp_f64(ac0 * winR[k + 1]); rr[P.bix + k + 1] = v; rr[P.bix - k - 1] = v; }
@@ -1335,9 +1413,10 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             // (tables stay in global memory: staging them in LDS per workgroup measured slower than L1 hits)
             P.mode = getenv("PCE_PITCH_LDS_FFT") ? 0
                      : (nfft == 1024 && P.rr_len <= R_WAVE_F64) ? 1
-                     : (nfft == 512 && P.rr_len <= R_WAVE_F64 / 2) ? 2 : 0;
+                     : (nfft == 512 && P.rr_len <= R_WAVE_F64 / 2) ? 2
+                     : (nfft == 2048 && P.rr_len <= R3_WAVE_F64) ? 3 : 0;
             P.fpb = P.mode == 2 ? 2 * PI_FPB : PI_FPB;
-            P.tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) != 0 : P.mode == 2;
+            P.tabs = P.mode == 3 ? 0 : getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) != 0 : P.mode == 2;   // MODE 3: 75 KB of exchange images leave no room
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
             for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
@@ -1349,15 +1428,16 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             PCE_HIP(c, c->pi_windowR.reserve(sizeof(double) * windowR.size()));
             PCE_HIP(c, hipMemcpyAsync(c->pi_window.p, window.data(), sizeof(double) * window.size(), hipMemcpyHostToDevice, c->stream));
             PCE_HIP(c, hipMemcpyAsync(c->pi_windowR.p, windowR.data(), sizeof(double) * windowR.size(), hipMemcpyHostToDevice, c->stream));
+            P.pcm_span = (((int)std::ceil((double)(P.fpb - 1) * P.dt / P.dx) + P.nw + 4) + 7) & ~7;   // samples under one work item's frames
             std::vector<double> blob;
             if (P.mode != 0) {
                 // lane-ordered tables for the register paths: tw1[k-1][l] = W_M^(l k), tw2[k-1][c] = W_M^(8 c k),
                 // twN[k] = W_N^k (k < M), window, windowR[0..bix]; every table starts on a 16-byte boundary
-                const int LW = P.mode == 2 ? 32 : 64, CW = LW / 8;
+                const int LW = P.mode == 2 ? 32 : 64, CW = LW / 8, NK1 = P.mode == 3 ? 16 : 8, S2 = P.mode == 3 ? 16 : 8;
                 auto W = [&](int m, int period) { return std::pair<double, double>(std::cos(2.0 * PI_D * m / period), -std::sin(2.0 * PI_D * m / period)); };
-                for (int k = 1; k < 8; k++) for (int l = 0; l < LW; l++) { auto w = W(l * k, Mc); blob.push_back(w.first); blob.push_back(w.second); }
+                for (int k = 1; k < NK1; k++) for (int l = 0; l < LW; l++) { auto w = W(l * k, Mc); blob.push_back(w.first); blob.push_back(w.second); }
                 P.o_tw2 = (int)blob.size();
-                for (int k = 1; k < 8; k++) for (int q = 0; q < CW; q++) { auto w = W(8 * q * k, Mc); blob.push_back(w.first); blob.push_back(w.second); }
+                for (int k = 1; k < 8; k++) for (int q = 0; q < CW; q++) { auto w = W(S2 * q * k, Mc); blob.push_back(w.first); blob.push_back(w.second); }
                 P.o_twN = (int)blob.size();
                 for (int k = 0; k < Mc; k++) { auto w = W(k, nfft); blob.push_back(w.first); blob.push_back(w.second); }
                 P.o_win = (int)blob.size();
@@ -1367,7 +1447,6 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                 for (int k = 0; k <= P.bix; k++) blob.push_back(windowR[(size_t)k]);
                 if (blob.size() & 1) blob.push_back(0.0);
                 P.blob_f64 = (int)blob.size();
-                P.pcm_span = (((int)std::ceil((double)(P.fpb - 1) * P.dt / P.dx) + P.nw + 4) + 7) & ~7;
                 PCE_HIP(c, c->pi_blob.reserve(sizeof(double) * blob.size()));
                 PCE_HIP(c, hipMemcpyAsync(c->pi_blob.p, blob.data(), sizeof(double) * blob.size(), hipMemcpyHostToDevice, c->stream));
             }
@@ -1436,12 +1515,13 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             nb = (nb + 7) & ~(int64_t)7;         // multiple of 8 so the XCD remap is a bijection; extra blocks exit
             // long windows (44.1 kHz at a 75 Hz floor: 72 KB per wavefront) run fewer wavefronts per workgroup
             int wpb = PI_WPB;
-            while (wpb > 1 && sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb > 160 * 1024) wpb >>= 1;
+            while (wpb > 1 && sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb + sizeof(int16_t) * (size_t)P.pcm_span > 160 * 1024) wpb >>= 1;
             if (P.mode != 0) wpb = PI_WPB;
-            const size_t lds = P.mode != 0 ? sizeof(double) * ((size_t)R_WAVE_F64 * PI_WPB + (P.tabs ? (size_t)P.blob_f64 : 0)) + sizeof(int16_t) * (size_t)P.pcm_span
-                                           : sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb;
+            const size_t lds = P.mode != 0 ? sizeof(double) * ((size_t)reg_wave_f64(P.mode) * PI_WPB + (P.tabs ? (size_t)P.blob_f64 : 0)) + sizeof(int16_t) * (size_t)P.pcm_span
+                                           : sizeof(double) * 4 * (size_t)P.zlen * (size_t)wpb + sizeof(int16_t) * (size_t)P.pcm_span;
             const void *kfn = P.mode == 1 ? (P.tabs ? reinterpret_cast<const void *>(k_pitch_frames<4, 1, true>) : reinterpret_cast<const void *>(k_pitch_frames<4, 1, false>))
                               : P.mode == 2 ? (P.tabs ? reinterpret_cast<const void *>(k_pitch_frames<4, 2, true>) : reinterpret_cast<const void *>(k_pitch_frames<4, 2, false>))
+                              : P.mode == 3 ? reinterpret_cast<const void *>(k_pitch_frames<4, 3, false>)
                               : wpb == 4 ? reinterpret_cast<const void *>(k_pitch_frames<4, 0, false>)
                               : wpb == 2 ? reinterpret_cast<const void *>(k_pitch_frames<2, 0, false>)
                                          : reinterpret_cast<const void *>(k_pitch_frames<1, 0, false>);
@@ -1466,6 +1546,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                 else if (P.mode == 1) launch(k_pitch_frames<4, 1, false>);
                 else if (P.mode == 2 && P.tabs) launch(k_pitch_frames<4, 2, true>);
                 else if (P.mode == 2) launch(k_pitch_frames<4, 2, false>);
+                else if (P.mode == 3) launch(k_pitch_frames<4, 3, false>);
                 else if (wpb == 4) launch(k_pitch_frames<4, 0, false>);
                 else if (wpb == 2) launch(k_pitch_frames<2, 0, false>);
                 else launch(k_pitch_frames<1, 0, false>);
