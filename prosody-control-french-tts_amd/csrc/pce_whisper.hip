@@ -334,7 +334,8 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
                 const float t = v[e] + bv[e];
                 o[e] = (bf16)(EPI == EPI_GELU_BF16 ? gelu_exact(t) : t);
             }
-            *reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16 *>(Cv) + cbase + (int64_t)(m0 + row) * ldc + n0 + cx) = o;
+            // written once, read by the next kernel: keep it out of the way of the operand tiles in L2
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8 *>(reinterpret_cast<bf16 *>(Cv) + cbase + (int64_t)(m0 + row) * ldc + n0 + cx));
         }
     } else {
         // fp32 outputs: 32 threads x 4 columns per row, 16 rows per pass
