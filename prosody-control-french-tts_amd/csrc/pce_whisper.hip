@@ -231,6 +231,15 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
         if (m0 >= M) return;                                                     // padding tile
     }
     const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0;
+    // the epilogue's bias values are fetched now: after the K loop their load latency (1-2 us) was fully exposed
+    constexpr bool OUT_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV);
+    float bv[8];
+    {
+        const int cx0 = OUT_BF16 ? (tid & 15) * 8 : (tid & 31) * 4;
+#pragma unroll
+        for (int e = 0; e < (OUT_BF16 ? 8 : 4); e++) bv[e] = bias ? bias[n0 + cx0 + e] : 0.f;
+    }
+    const float bv_col = (EPI == EPI_QKV && bias) ? bias[n0 + (tid & 127)] : 0.f;      // transposed-V path: one column per thread
     A += (int64_t)blockIdx.z * a_batch;
     f32x4 acc[4][2];
 #pragma unroll
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
         const int dmodel = N - v_col0, S = pos_T;                   // V is the last d_model columns
         const int cc = tid & 127, rg = tid >> 7;                  // one column, 8-row groups
         const int n = n0 + cc - v_col0, head = n >> 6, dd = n & 63;
-        const float bv = bias ? bias[n0 + cc] : 0.f;
+        const float bv = bv_col;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int row = rg * 8 + 32 * p;
@@ -318,9 +327,6 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
     } else if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV) {
         // 16 threads x 8 columns per row, 32 rows per pass
         const int cx = (tid & 15) * 8, ry = tid >> 4;
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) bv[e] = bias ? bias[n0 + cx + e] : 0.f;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const int row = ry + 32 * p;
@@ -340,9 +346,15 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
     } else {
         // fp32 outputs: 32 threads x 4 columns per row, 16 rows per pass
         const int cx = (tid & 31) * 4, ry = tid >> 5;
-        float bv[4];
+        float4 oldv[8];
+        if (EPI == EPI_RESID_F32) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) bv[e] = bias ? bias[n0 + cx + e] : 0.f;
+            for (int p = 0; p < 8; p++) {                         // all eight residual loads in flight together
+                const int row = ry + 16 * p;
+                oldv[p] = m0 + row < M ? *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(Cv) + cbase + (int64_t)(m0 + row) * ldc + n0 + cx)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             const int row = ry + 16 * p;
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
                 o = make_float4(gelu_exact(v.x + bv[0]) + pe.x, gelu_exact(v.y + bv[1]) + pe.y, gelu_exact(v.z + bv[2]) + pe.z,
                                 gelu_exact(v.w + bv[3]) + pe.w);
             } else {
-                const float4 old = *dst;
+                const float4 old = oldv[p];
                 o = make_float4(old.x + v.x + bv[0], old.y + v.y + bv[1], old.z + v.z + bv[2], old.w + v.w + bv[3]);
             }
             *dst = o;
