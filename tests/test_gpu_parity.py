@@ -169,3 +169,21 @@ def test_c1_real_speech_clip_all_measurements(engine):
     assert got.shape == ws.shape == (513, 313)                # 513 x 313 at 5 s
     live = (ws > -79.9) & (got > -79.9)
     assert np.max(np.abs(got[live] - ws[live])) <= 2e-2
+
+
+@pytest.mark.parametrize("rate,floor", [(48000, 150.0), (22050, 75.0), (44100, 100.0), (8000, 75.0)])
+def test_pitch_other_rates_match_oracle(engine, rate, floor):
+    """The transform path depends on N = nsampFFT: 2048 (register path, 16 points per lane) at 48 kHz / 150 Hz,
+    22.05 kHz / 75 Hz and 44.1 kHz / 100 Hz; 512 at 8 kHz / 75 Hz.  Same tolerance as the 16 kHz test."""
+    from prosody_control_french_tts_amd import synth
+    clips = [synth.synth_clip(i, 2.0, rate) for i in range(3)]
+    engine.upload(clips, rate)
+    res = engine.pitch(engine.whole_clip_slices(), E.PitchParams.praat(floor, 600.0), want_f0=True, want_strength=True)
+    off = res["frame_offsets"]
+    for i, c in enumerate(clips):
+        want = O.pitch_ac(c.astype(np.float64) / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(floor, 600.0))
+        f0 = res["f0"][off[i]:off[i + 1]]; sg = res["strength"][off[i]:off[i + 1]]
+        v = want["f0"] > 0
+        assert len(f0) == len(want["f0"]) and np.array_equal(f0 > 0, v) and v.sum() > 10
+        assert np.max(np.abs(f0[v] - want["f0"][v]) / want["f0"][v]) <= 1e-6
+        assert np.max(np.abs(sg[v] - want["strength"][v])) <= 1e-6
