@@ -80,8 +80,9 @@ __device__ __forceinline__ void load_const(StConst &c, const float *__restrict__
     for (int t = 0; t < 9; t++) c.twu[t] = g1024[min(lane + 64 * t, MC)];
 }
 
-// One frame.  zb: this wave's LDS buffer.  Calls sink(k, magnitude) for k = lane + 64 t (t = 0..7) and k = 512 on lane 0.
-template <class Sink>
+// One frame.  zb: this wave's LDS buffer.  Calls sink(k, magnitude) for k = lane + 64 t (t = 0..7) and k = 512 on lane 0;
+// with SQUARED the sink receives |X|^2 (the maximum pass: sqrt is monotone, one square root per clip instead of 9 per lane and frame).
+template <bool SQUARED, class Sink>
 __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, const StClip &cl, int frame, int hop, const StConst &C,
                                            float2 *zb, int lane, Sink sink)
 {
@@ -148,7 +149,8 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
         const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
         const float2 x = cadd(e, cmul(C.twu[t], o));
-        sink(k, sqrtf(x.x * x.x + x.y * x.y));      // |x| <= 1024: no overflow; np.abs differs by <= 1 ulp
+        const float p2 = x.x * x.x + x.y * x.y;
+        sink(k, SQUARED ? p2 : sqrtf(p2));           // |x| <= 1024: no overflow; np.abs differs by <= 1 ulp
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_max(const int16_t *__restri
         for (int fr = wv; fr < F; fr += WAVES) {
             const int frame = tl.frame0 + fr;
             if (frame >= cl.n_frames) break;
-            stft_frame(pcm, cl, frame, hop, C, zbuf[wv], lane, [&](int, float mag) { m = fmaxf(m, mag); });
+            stft_frame<true>(pcm, cl, frame, hop, C, zbuf[wv], lane, [&](int, float mag2) { m = fmaxf(m, mag2); });
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_max(const int16_t *__restri
     if (tid == 0 && bid < n_tiles) {
         float r = 0.f;
         for (int i = 0; i < WAVES; i++) r = fmaxf(r, red[i]);
-        atomicMax(clip_max + clip, __float_as_uint(r));            // non-negative floats order as their bit patterns
+        atomicMax(clip_max + clip, __float_as_uint(sqrtf(r)));     // non-negative floats order as their bit patterns; sqrt(max |X|^2) = max |X|
     }
 }
 
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_db(const int16_t *__restric
     const float floor_db = 0.0f - top_db;
     const int nfr = min(F, cl.n_frames - tl.frame0);
     for (int fr = wv; fr < nfr; fr += WAVES) {
-        stft_frame(pcm, cl, tl.frame0 + fr, hop, C, zbuf[wv], lane, [&](int k, float mag) {
+        stft_frame<false>(pcm, cl, tl.frame0 + fr, hop, C, zbuf[wv], lane, [&](int k, float mag) {
             const float pw = mag * mag;
             float db = 10.0f * __log10f(fmaxf(amin2, pw));
             db -= ref_db;

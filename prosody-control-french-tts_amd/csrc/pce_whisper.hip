@@ -1284,6 +1284,9 @@ int pce_whisper_align_run(pce_ctx *c, const int32_t *tokens, const int32_t *toke
     PCE_HIP(c, w->d_ln.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
     PCE_HIP(c, w->d_qk.reserve(sizeof(bf16) * (size_t)Mt * 2 * d + 4096));
     PCE_HIP(c, w->d_attn.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    // k_attention writes the rows of real tokens only: the pad rows (T..T_pad of every clip) must not hold stale bits, a NaN
+    // there would reach the next layer's V^T and poison valid queries through 0 * NaN (seen as an intermittent NaN cost matrix)
+    PCE_HIP(c, hipMemsetAsync(w->d_attn.p, 0, sizeof(bf16) * (size_t)Mt * d + 4096, c->stream));
     PCE_HIP(c, w->d_q.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
     PCE_HIP(c, w->d_hidden.reserve(sizeof(bf16) * (size_t)Mt * 4 * d + 4096));
     PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)Ma * d + 4096));
