@@ -53,6 +53,19 @@ def _cpu_one(args):
     return len(c)
 
 
+def load_pmc_valu(kernel):
+    """Mean SQ_INSTS_VALU per launch of `kernel` from the committed rocprofv3 --pmc pass of this command."""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_sq_counter_collection.csv")
+    try:
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                if r["Counter_Name"] == "SQ_INSTS_VALU" and re.search(r"\b" + kernel + r"\b", r["Kernel_Name"])]
+        return sum(vals) / len(vals) if vals else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(clips, rate, budget_clips):
     """The CPU oracle ("port": C double-precision restatement) on a bounded sample: one thread (`value`, the
     contract's figure) and, as `all_cores`, utterance-parallel over the host's cores the way the reference runs
@@ -241,7 +254,15 @@ def main():
                         "peak": r0["peak"], "unit": r0["unit"], "frac": r0["frac"], "traffic": t0,
                         "note": "dominant stage by device time; `achieved` = the stage's algorithmic bytes (or flops) / the device time "
                                 "of the stage's kernels.  The F0 stage is fp64-VALU bound (about 1e3 flop per algorithmic byte, "
-                                "DESIGN.md section 3): its HBM fraction is small by construction; `stages` lists every stage."}
+                                "DESIGN.md section 3): its HBM fraction is small by construction; `stages` lists every stage.  "
+                                "Issue-slot view of the dominant kernel (profiles/r01/pmc_sq_counter_collection.csv): "
+                                "`valu_f64` prices k_pitch_refine's SQ_INSTS_VALU at the measured 4.6 cycles per fp64 wave-instruction "
+                                "against the 1024 SIMDs' issue capacity over the kernel's duration.",
+                        "valu_f64": {"kernel": "k_pitch_refine", "insts_valu_per_launch": load_pmc_valu("k_pitch_refine"), "cycles_per_inst": 4.6,
+                                     "simds": 1024, "clock_ghz": 2.1,
+                                     "issue_frac": ((load_pmc_valu("k_pitch_refine") or 0.0) * 4.6 / (1024 * 2.1e9)) / max(kt["k_pitch_refine"]["avg_ms"] * 1e-3, 1e-9)
+                                     if "k_pitch_refine" in kt else None,
+                                     "source": "SQ_INSTS_VALU from profiles/r01 (separate rocprofv3 --pmc pass of this command)"}}
         info = eng.device_info()
         print(json.dumps({
             "metric": "audio-seconds/sec prosody+align throughput, 16 kHz French",
