@@ -1564,18 +1564,19 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             unsigned int *run_count = c->pi_runs.as<unsigned int>();
             PathRun *runs = reinterpret_cast<PathRun *>(c->pi_runs.as<char>() + rc_bytes);
             const unsigned int run_cap = (unsigned int)(total / RUN_LISTS + 64);
-            PCE_HIP(c, hipMemsetAsync(run_count, 0, rc_bytes, c->stream));
+            // everything after the refinement (local terms, path finder, median) goes to the side stream: it is HBM- and
+            // latency-bound, and whatever the caller launches next on the main stream runs beside it; every consumer
+            // joins first (pce_side_join)
+            { int rc2 = pce_side_begin(c, pce_ctx::SIDE_TAIL, &tail); if (rc2) return rc2; }
+            PCE_HIP(c, hipMemsetAsync(run_count, 0, rc_bytes, tail));
             const long long ne = total * PI_MAXC;
             {
-                KernelTimer t(c, PCE_K_PITCH_DELTA);
-                hipLaunchKernelGGL(k_pitch_delta, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, c->stream, P, c->pi_meta.as<PiSlice>(),
+                KernelTimer t(c, PCE_K_PITCH_DELTA, tail);
+                hipLaunchKernelGGL(k_pitch_delta, dim3((unsigned)div_up(ne, 256)), dim3(256), 0, tail, P, c->pi_meta.as<PiSlice>(),
                                    c->pi_fslice.as<int>(), c->pi_cand.as<double>(), ncand, intensity, (long long)total,
                                    c->pi_dl.as<double2>(), c->pi_f0.as<double>(), c->pi_strength.as<double>(), runs, run_count, run_cap);
             }
             {
-                // the tail (path finder, median) is latency bound: it goes to the auxiliary stream, so whatever the
-                // caller launches next on the main stream runs beside it; every consumer joins first (pce_join_aux)
-                { int rc2 = pce_side_begin(c, pce_ctx::SIDE_TAIL, &tail); if (rc2) return rc2; }
                 KernelTimer t(c, PCE_K_PITCH_PATH, tail);
                 const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 16u;     // multiple of RUN_LISTS
                 hipLaunchKernelGGL(k_pitch_path, dim3(blocks), dim3(64), 0, tail, P,
