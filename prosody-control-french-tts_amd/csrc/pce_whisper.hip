@@ -198,109 +198,24 @@ __device__ __forceinline__ void stage_tile(const bf16 *__restrict__ G, int64_t l
     }
 }
 
-// 8 wavefronts as 2 (M) x 4 (N), each owning a 64 x 32 slice of the 128 x 128 tile.  Three LDS stages:
-// while tile kt is multiplied, tiles kt+1 and kt+2 are in flight as LDS-DMA (4 instructions per wave and
-// tile), so a tile has two full K-steps to arrive.  The barrier is a raw s_barrier behind a COUNTED
-// s_waitcnt vmcnt(4): __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring.
 template <int EPI>
-__global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
-                                                        const bf16 *__restrict__ B, int M, int N, int K,
-                                                        const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
-                                                        const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles, unsigned long long *trace)
+__device__ __forceinline__ void gemm_fetch_bias(const float *__restrict__ bias, int n0, int tid, float (&bv)[8], float &bv_col)
 {
-    // operand ring [stage][A|B][128][64] bf16, re-used as the fp32 epilogue tile [128][G_TLD]
-    constexpr int SMEM_ELEMS = (G_STAGES * 2 * G_BM * G_BK * 2 > G_BM * G_TLD * 4 ? G_STAGES * 2 * G_BM * G_BK : G_BM * G_TLD * 2);
-    __shared__ __attribute__((aligned(1024))) bf16 smem[SMEM_ELEMS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 2, wc = wv & 3;
-    // XCD-aware, L2-sized tile order.  Workgroups go to the 8 XCDs round-robin, so XCD x is given a contiguous range of
-    // the tile sequence, and the ~64 workgroups resident on an XCD at a time are 64 consecutive tiles of it.  The
-    // sequence walks SUPERTILES of sm (M) x sn (N) tiles: their operands (sm A row blocks + sn B row blocks of 128 x K)
-    // fit the XCD's 4 MB L2 and every block is re-read 8 times from it.  (A plain row-major sequence keeps 2-3 A blocks
-    // and ALL of B live: at N = 3072 that is 4.7 MB of weights, which evicts itself; measured L2 hit rate 50 %.)
-    const int tiles_n = (int)gridDim.x, tiles_m_pad = (int)gridDim.y;          // gridDim.y is padded to a multiple of 8
-    int lin = (int)blockIdx.y * tiles_n + (int)blockIdx.x;
-    const int total = tiles_n * tiles_m_pad;
-    if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
-    int m0, n0;
-    {
-        const int per = sm_tiles * sn_tiles, sup = lin / per, r = lin - sup * per;
-        const int n_sn = tiles_n / sn_tiles;
-        const int tm = (sup / n_sn) * sm_tiles + r / sn_tiles, tn = (sup % n_sn) * sn_tiles + r % sn_tiles;
-        m0 = tm * G_BM; n0 = tn * G_BN;
-        if (m0 >= M) return;                                                     // padding tile
-    }
-    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0;
-    // the epilogue's bias values are fetched now: after the K loop their load latency (1-2 us) was fully exposed
     constexpr bool OUT_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV);
-    float bv[8];
-    {
-        const int cx0 = OUT_BF16 ? (tid & 15) * 8 : (tid & 31) * 4;
+    const int cx0 = OUT_BF16 ? (tid & 15) * 8 : (tid & 31) * 4;
 #pragma unroll
-        for (int e = 0; e < (OUT_BF16 ? 8 : 4); e++) bv[e] = bias ? bias[n0 + cx0 + e] : 0.f;
-    }
-    const float bv_col = (EPI == EPI_QKV && bias) ? bias[n0 + (tid & 127)] : 0.f;      // transposed-V path: one column per thread
-    A += (int64_t)blockIdx.z * a_batch;
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fq = lane >> 4;
-    const int nk = K / G_BK;
-    constexpr int STAGE = 2 * G_BM * G_BK;
-    stage_tile(A, lda, m0, M - 1, 0, smem, wv, lane);
-    stage_tile(B, K, n0, N - 1, 0, smem + G_BM * G_BK, wv, lane);
-    if (G_STAGES > 2 && nk > 1) {
-        stage_tile(A, lda, m0, M - 1, G_BK, smem + STAGE, wv, lane);
-        stage_tile(B, K, n0, N - 1, G_BK, smem + STAGE + G_BM * G_BK, wv, lane);
-    }
-    for (int kt = 0; kt < nk; kt++) {
-        const bf16 *sA = smem + (kt % G_STAGES) * STAGE, *sB = sA + G_BM * G_BK;
-        // tile kt has landed once at most the 4 youngest DMAs of this wave (tile kt+1) are outstanding
-        if (G_STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + G_STAGES - 1 < nk) {                        // refill the stage tile kt-1 has just released
-            bf16 *nA = smem + ((kt + G_STAGES - 1) % G_STAGES) * STAGE;
-            stage_tile(A, lda, m0, M - 1, (kt + G_STAGES - 1) * G_BK, nA, wv, lane);
-            stage_tile(B, K, n0, N - 1, (kt + G_STAGES - 1) * G_BK, nA + G_BM * G_BK, wv, lane);
-        }
-#pragma unroll
-        for (int kk = 0; kk < G_BK; kk += 32) {
-            bf16x8 a[4], b[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int row = wr * 64 + i * 16 + fr;
-                a[i] = *reinterpret_cast<const bf16x8 *>(&sA[row * G_BK + swz_chunk(row, (kk >> 3) + fq) * 8]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int row = wc * 32 + j * 16 + fr;
-                b[j] = *reinterpret_cast<const bf16x8 *>(&sB[row * G_BK + swz_chunk(row, (kk >> 3) + fq) * 8]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    const unsigned long long t_loop = trace ? __builtin_amdgcn_s_memtime() : 0;
-    // epilogue.  The accumulator layout (col = lane & 15, row = (lane >> 4) * 4 + reg) would store 2-byte
-    // elements 32 B at a time; measured, such an epilogue cost more than the whole K loop.  The tile
-    // goes through LDS instead (the operand ring is free now) and leaves as full 256-B row segments.
-    __builtin_amdgcn_s_barrier();                           // every wave is done reading the operand stages
-    float *tile = reinterpret_cast<float *>(smem);           // [128][G_TLD] fp32 = 66 KiB
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                tile[(wr * 64 + i * 16 + fq * 4 + r) * G_TLD + wc * 32 + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
-    const unsigned long long t_tile = trace ? __builtin_amdgcn_s_memtime() : 0;
-    const int64_t cbase = (int64_t)blockIdx.z * c_batch;
+    for (int e = 0; e < 8; e++) bv[e] = (bias && e < (OUT_BF16 ? 8 : 4)) ? bias[n0 + cx0 + e] : 0.f;
+    bv_col = (EPI == EPI_QKV && bias) ? bias[n0 + (tid & 127)] : 0.f;      // transposed-V path: one column per thread
+}
+
+// Output stage shared by the GEMM kernels: a [128][G_TLD] fp32 tile in LDS (rows m0.., columns n0..) leaves as full
+// 256-byte row segments with the fused bias / GELU / positional add / residual accumulate / transposed-V write.
+// bv / bv_col: this thread's bias values for the tile's columns, fetched by the caller before its K loop.
+template <int EPI>
+__device__ __forceinline__ void gemm_store_tile(const float *tile, int tid, int m0, int n0, int M, int N, const float (&bv)[8], float bv_col,
+                                                void *__restrict__ Cv, int64_t ldc, int64_t cbase, const float *__restrict__ pos, int pos_T,
+                                                int v_col0, int vt_sp)
+{
     if (EPI == EPI_QKV && n0 >= v_col0) {
         // V columns: written transposed, vt[clip][head][d][key], so the attention kernel can stage V^T tiles
         // (8 keys contiguous per d) without an LDS transpose.  `pos` carries the vt pointer, pos_T = S.
@@ -373,10 +288,215 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
             *dst = o;
         }
     }
+}
+
+// 8 wavefronts as 2 (M) x 4 (N), each owning a 64 x 32 slice of the 128 x 128 tile.  Three LDS stages:
+// while tile kt is multiplied, tiles kt+1 and kt+2 are in flight as LDS-DMA (4 instructions per wave and
+// tile), so a tile has two full K-steps to arrive.  The barrier is a raw s_barrier behind a COUNTED
+// s_waitcnt vmcnt(4): __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring.
+template <int EPI>
+__global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
+                                                        const bf16 *__restrict__ B, int M, int N, int K,
+                                                        const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
+                                                        const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles, unsigned long long *trace)
+{
+    // operand ring [stage][A|B][128][64] bf16, re-used as the fp32 epilogue tile [128][G_TLD]
+    constexpr int SMEM_ELEMS = (G_STAGES * 2 * G_BM * G_BK * 2 > G_BM * G_TLD * 4 ? G_STAGES * 2 * G_BM * G_BK : G_BM * G_TLD * 2);
+    __shared__ __attribute__((aligned(1024))) bf16 smem[SMEM_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;
+    // XCD-aware, L2-sized tile order.  Workgroups go to the 8 XCDs round-robin, so XCD x is given a contiguous range of
+    // the tile sequence, and the ~64 workgroups resident on an XCD at a time are 64 consecutive tiles of it.  The
+    // sequence walks SUPERTILES of sm (M) x sn (N) tiles: their operands (sm A row blocks + sn B row blocks of 128 x K)
+    // fit the XCD's 4 MB L2 and every block is re-read 8 times from it.  (A plain row-major sequence keeps 2-3 A blocks
+    // and ALL of B live: at N = 3072 that is 4.7 MB of weights, which evicts itself; measured L2 hit rate 50 %.)
+    const int tiles_n = (int)gridDim.x, tiles_m_pad = (int)gridDim.y;          // gridDim.y is padded to a multiple of 8
+    int lin = (int)blockIdx.y * tiles_n + (int)blockIdx.x;
+    const int total = tiles_n * tiles_m_pad;
+    if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    int m0, n0;
+    {
+        const int per = sm_tiles * sn_tiles, sup = lin / per, r = lin - sup * per;
+        const int n_sn = tiles_n / sn_tiles;
+        const int tm = (sup / n_sn) * sm_tiles + r / sn_tiles, tn = (sup % n_sn) * sn_tiles + r % sn_tiles;
+        m0 = tm * G_BM; n0 = tn * G_BN;
+        if (m0 >= M) return;                                                     // padding tile
+    }
+    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memtime() : 0;
+    // the epilogue's bias values are fetched now: after the K loop their load latency (1-2 us) was fully exposed
+    float bv[8]; float bv_col;
+    gemm_fetch_bias<EPI>(bias, n0, tid, bv, bv_col);
+    A += (int64_t)blockIdx.z * a_batch;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = K / G_BK;
+    constexpr int STAGE = 2 * G_BM * G_BK;
+    stage_tile(A, lda, m0, M - 1, 0, smem, wv, lane);
+    stage_tile(B, K, n0, N - 1, 0, smem + G_BM * G_BK, wv, lane);
+    if (G_STAGES > 2 && nk > 1) {
+        stage_tile(A, lda, m0, M - 1, G_BK, smem + STAGE, wv, lane);
+        stage_tile(B, K, n0, N - 1, G_BK, smem + STAGE + G_BM * G_BK, wv, lane);
+    }
+    for (int kt = 0; kt < nk; kt++) {
+        const bf16 *sA = smem + (kt % G_STAGES) * STAGE, *sB = sA + G_BM * G_BK;
+        // tile kt has landed once at most the 4 youngest DMAs of this wave (tile kt+1) are outstanding
+        if (G_STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + G_STAGES - 1 < nk) {                        // refill the stage tile kt-1 has just released
+            bf16 *nA = smem + ((kt + G_STAGES - 1) % G_STAGES) * STAGE;
+            stage_tile(A, lda, m0, M - 1, (kt + G_STAGES - 1) * G_BK, nA, wv, lane);
+            stage_tile(B, K, n0, N - 1, (kt + G_STAGES - 1) * G_BK, nA + G_BM * G_BK, wv, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < G_BK; kk += 32) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = wr * 64 + i * 16 + fr;
+                a[i] = *reinterpret_cast<const bf16x8 *>(&sA[row * G_BK + swz_chunk(row, (kk >> 3) + fq) * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int row = wc * 32 + j * 16 + fr;
+                b[j] = *reinterpret_cast<const bf16x8 *>(&sB[row * G_BK + swz_chunk(row, (kk >> 3) + fq) * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const unsigned long long t_loop = trace ? __builtin_amdgcn_s_memtime() : 0;
+    // epilogue.  The accumulator layout (col = lane & 15, row = (lane >> 4) * 4 + reg) would store 2-byte
+    // elements 32 B at a time; measured, such an epilogue cost more than the whole K loop.  The tile
+    // goes through LDS instead (the operand ring is free now) and leaves as full 256-B row segments.
+    __builtin_amdgcn_s_barrier();                           // every wave is done reading the operand stages
+    float *tile = reinterpret_cast<float *>(smem);           // [128][G_TLD] fp32 = 66 KiB
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                tile[(wr * 64 + i * 16 + fq * 4 + r) * G_TLD + wc * 32 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const unsigned long long t_tile = trace ? __builtin_amdgcn_s_memtime() : 0;
+    gemm_store_tile<EPI>(tile, tid, m0, n0, M, N, bv, bv_col, Cv, ldc, (int64_t)blockIdx.z * c_batch, pos, pos_T, v_col0, vt_sp);
     if (trace && tid == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         unsigned long long *o = trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         o[0] = t_start; o[1] = t_loop; o[2] = t_tile; o[3] = t_end;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 128 x 256 tile variant for wide outputs (N >= 2048: QKV, fc1).  Skipping the A-operand loads of the 128 x 128 kernel
+// speeds the encoder up by 36 %, skipping the B loads by 12 % (ablation): the ACTIVATION stream is what these launches
+// wait for.  A tile twice as wide reads every A row block half as often; the weights (B) stay L2-resident anyway.
+// 8 waves as 2 (M) x 4 (N), 64 x 64 per wave, 32-deep K-steps (16 MFMAs per wave between barriers, as before), two
+// 24 KB stages so that two workgroups still share a CU, and the output leaves through the same 128 x 128 LDS tile
+// in two column passes.
+// ---------------------------------------------------------------------------
+constexpr int W_BN = 256, W_BK = 32;
+constexpr int W_STAGE = (G_BM + W_BN) * W_BK;                   // bf16 elements per stage (24 KB)
+__device__ __forceinline__ int swz32(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }   // 64-byte rows (see swz_chunk)
+// ROWS x 32 k operand tile: wave-instructions of 1 KiB (16 rows each)
+template <int ROWS>
+__device__ __forceinline__ void stage_rows32(const bf16 *__restrict__ G, int64_t ld, int row0, int row_max, int k0, bf16 *lds_tile, int wv, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS / 128; i++) {
+        const int r0 = (wv + 8 * i) * 16;
+        const int row = r0 + (lane >> 2);
+        const int c = swz32(row, lane & 3);
+        int gr = row0 + row; if (gr > row_max) gr = row_max;
+        const bf16 *src = G + (int64_t)gr * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + r0 * W_BK), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(G_THREADS, 4) void k_gemm_wide(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
+                                                        const bf16 *__restrict__ B, int M, int N, int K,
+                                                        const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
+                                                        const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles)
+{
+    constexpr int SMEM_ELEMS = (2 * W_STAGE * 2 > G_BM * G_TLD * 4 ? 2 * W_STAGE : G_BM * G_TLD * 2);
+    __shared__ __attribute__((aligned(1024))) bf16 smem[SMEM_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;                         // 2 x 4 waves, 64 x 64 each
+    const int tiles_n = (int)gridDim.x, tiles_m_pad = (int)gridDim.y;
+    int lin = (int)blockIdx.y * tiles_n + (int)blockIdx.x;
+    const int total = tiles_n * tiles_m_pad;
+    if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    int m0, n0;
+    {
+        const int per = sm_tiles * sn_tiles, sup = lin / per, r = lin - sup * per;
+        const int n_sn = tiles_n / sn_tiles;
+        const int tm = (sup / n_sn) * sm_tiles + r / sn_tiles, tn = (sup % n_sn) * sn_tiles + r % sn_tiles;
+        m0 = tm * G_BM; n0 = tn * W_BN;
+        if (m0 >= M) return;
+    }
+    float bv0[8], bv1[8]; float bc0, bc1;
+    gemm_fetch_bias<EPI>(bias, n0, tid, bv0, bc0);
+    gemm_fetch_bias<EPI>(bias, n0 + 128, tid, bv1, bc1);
+    A += (int64_t)blockIdx.z * a_batch;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nk = K / W_BK;
+    stage_rows32<G_BM>(A, lda, m0, M - 1, 0, smem, wv, lane);
+    stage_rows32<W_BN>(B, K, n0, N - 1, 0, smem + G_BM * W_BK, wv, lane);
+    for (int kt = 0; kt < nk; kt++) {
+        const bf16 *sA = smem + (kt & 1) * W_STAGE, *sB = sA + G_BM * W_BK;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) {
+            bf16 *nA = smem + ((kt + 1) & 1) * W_STAGE;
+            stage_rows32<G_BM>(A, lda, m0, M - 1, (kt + 1) * W_BK, nA, wv, lane);
+            stage_rows32<W_BN>(B, K, n0, N - 1, (kt + 1) * W_BK, nA + G_BM * W_BK, wv, lane);
+        }
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = wr * 64 + i * 16 + fr;
+            a[i] = *reinterpret_cast<const bf16x8 *>(&sA[row * W_BK + swz32(row, fq) * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = wc * 64 + j * 16 + fr;
+            b[j] = *reinterpret_cast<const bf16x8 *>(&sB[row * W_BK + swz32(row, fq) * 8]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float *tile = reinterpret_cast<float *>(smem);               // [128][G_TLD] fp32: one half of the columns per pass
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        __syncthreads();                                         // operand reads (p = 0) / the first pass's tile reads are done
+        if ((wc >> 1) == p) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        tile[(wr * 64 + i * 16 + fq * 4 + r) * G_TLD + (wc & 1) * 64 + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (p == 0) gemm_store_tile<EPI>(tile, tid, m0, n0, M, N, bv0, bc0, Cv, ldc, (int64_t)blockIdx.z * c_batch, pos, pos_T, v_col0, vt_sp);
+        else gemm_store_tile<EPI>(tile, tid, m0, n0 + 128, M, N, bv1, bc1, Cv, ldc, (int64_t)blockIdx.z * c_batch, pos, pos_T, v_col0, vt_sp);
     }
 }
 
@@ -901,6 +1021,18 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
     int sn = 1;
     for (int cand : {8, 6, 4, 3, 2}) if (tiles_n % cand == 0) { sn = cand; break; }        // supertile width (divides the N tiles)
     static const int sm_env = getenv("PCE_GEMM_SM") ? atoi(getenv("PCE_GEMM_SM")) : 0, sn_env = getenv("PCE_GEMM_SN") ? atoi(getenv("PCE_GEMM_SN")) : 0;
+    static const int wide_env = getenv("PCE_GEMM_WIDE") ? atoi(getenv("PCE_GEMM_WIDE")) : -1;
+    const bool wide_ok = N % W_BN == 0 && K % W_BK == 0 && (int64_t)M * batch >= 4096 && (EPI != EPI_QKV || v_col0 % W_BN == 0);
+    if (wide_ok && (wide_env > 0 || (wide_env < 0 && N >= 1536))) {      // wide outputs (QKV, fc1; from N = 1536 so that the tiny model exercises it in the tests)
+        const int wt = N / W_BN;
+        int wsn = 1;
+        for (int cand : {4, 3, 2}) if (wt % cand == 0) { wsn = cand; break; }
+        const int wsm = 16;
+        dim3 wgrid((unsigned)wt, (unsigned)(div_up(M, G_BM * wsm) * wsm), (unsigned)batch);
+        hipLaunchKernelGGL((k_gemm_wide<EPI>), wgrid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
+                           v_col0, vt_sp, wsn, wsm);
+        return;
+    }
     int sm = sm_env > 0 ? sm_env : 16;                     // 16 x sn measured best by a hair (645-656 TFLOP/s over 4..16 x 2..8)
     if (sn_env > 0 && tiles_n % sn_env == 0) sn = sn_env;
     dim3 grid((unsigned)tiles_n, (unsigned)(div_up(M, G_BM * sm) * sm), (unsigned)batch);
