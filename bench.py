@@ -141,6 +141,12 @@ def main():
         from prosody_control_french_tts_amd import whisper_weights as WW
         wdims = WW.DIMS["small"]
         eng.whisper_load(wdims, WW.pack(WW.synthetic_weights(wdims), wdims))       # random-init weights of the architecture
+        tdims = WW.TEXT_DIMS["small"]
+        eng.whisper_decoder_load(tdims, WW.pack_decoder(WW.synthetic_decoder_weights(tdims), tdims))
+        trng = np.random.default_rng(5)
+        sot_len = 3                                    # <|sot|><|fr|><|transcribe|> ... <|eot|>: synthetic ids of a 10 s utterance's length
+        align_tokens = [trng.integers(0, tdims["n_vocab"], size=int(trng.integers(24, 48))).tolist() for _ in range(args.clips)]
+        align_frames = [n_samples // 160] * args.clips
 
     # One step = one pass of the hot path over the batch: launch() enqueues every kernel of the pass and the
     # asynchronous copy of the per-utterance statistics; finish() waits for that copy only, builds the 7-stat
@@ -150,6 +156,7 @@ def main():
         if wdims:
             eng.logmel_run(wdims["n_mels"])
             eng.whisper_encode_run()
+            eng.whisper_align_run(align_tokens, align_frames, sot_len)   # teacher-forced decoder + cross-attention weights + DTW
         eng.energy_run(sl, 500)
         eng.lufs_run(sl)
         eng.pitch_run(sl, params)
@@ -226,6 +233,7 @@ def main():
                                  + L * (2.0 * 1500 * d * 3 * d + 4.0 * 1500 * 1500 * d + 2.0 * 1500 * d * d + 16.0 * 1500 * d * d))
             stages += [("log-mel (R8)", ["k_logmel"], pcm + 80 * 3000 * 4.0 * args.clips, None),
                        ("whisper-small encoder (R8)", ["whisper_encoder"], None, flop)]
+            # (the forced-alignment leg -- decoder over 24-48 tokens per clip, alignment heads, DTW -- is timed as `whisper_align` in `kernels`)
         # k_energy runs three times per step (gate, LUFS peak, pitch peak): split its time over the users
         rows = []
         for name, ks, nbytes, flops in stages:
@@ -271,7 +279,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, "
                                    "energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256; "
-                                   + ("+ log-mel + Whisper-small encoder (synthetic weights, bf16 MFMA)" if wdims else "Whisper-encoder alignment (C3) not included: --workload c3"),
+                                   + ("+ log-mel + Whisper-small encoder + teacher-forced decoder / cross-attention DTW alignment (synthetic weights and token ids, bf16 MFMA)" if wdims else "Whisper-encoder alignment (C3) not included: --workload c3"),
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip"},
             "roofline": roofline, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,

@@ -371,6 +371,15 @@ class ProsodyEngine:
         self._tdims = WhisperTextDims(dims["n_vocab"], dims["n_text_ctx"], dims["n_state"], dims["n_head"], dims["n_layer"])
         self._check(self._lib.pce_whisper_decoder_load(self._ctx, C.byref(self._tdims), w.ctypes.data, w.size))
 
+    def whisper_align_run(self, token_lists, num_frames, sot_len: int, head_mask=None, medfilt_width: int = 7, qk_scale: float = 1.0):
+        """Enqueue the forced alignment (decoder, cross-attention weights, DTW) without fetching anything."""
+        toks = np.concatenate([np.asarray(t, dtype=np.int32) for t in token_lists]).astype(np.int32)
+        off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
+        nf = np.ascontiguousarray(num_frames, dtype=np.int32)
+        hm = None if head_mask is None else np.ascontiguousarray(head_mask, dtype=np.uint8)
+        self._check(self._lib.pce_whisper_align_run(self._ctx, toks.ctypes.data, off.ctypes.data, nf.ctypes.data, int(sot_len),
+                                                    hm.ctypes.data if hm is not None else None, int(medfilt_width), float(qk_scale)))
+
     def whisper_align(self, token_lists, num_frames, sot_len: int, head_mask=None, medfilt_width: int = 7, qk_scale: float = 1.0,
                       want_cost: bool = False):
         """Forced alignment of the given token sequences (one per clip, specials included) against the encoded audio.
