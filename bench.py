@@ -225,7 +225,7 @@ def main():
             ("lufs (R4)", ["k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate"], pcm, None),
             ("f0 (R1: Praat AC + path + median)", ["k_pitch_frames", "k_pitch_refine", "k_pitch_delta", "k_pitch_path", "k_pitch_median"],
              pcm + f0_out, None),
-            ("stft-dB (R10)", ["k_stft_max", "k_stft_db"], pcm + stft_out, None),
+            ("stft-dB (R10)", ["k_stft_max", "k_stft_db", "k_stft_norm"], pcm + stft_out, None),
         ]
         if wdims:
             d, L = wdims["n_state"], wdims["n_layer"]

@@ -114,6 +114,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
         c->own_stream = true;
     }
     c->no_side = getenv("PCE_NO_AUX") != nullptr;
+    c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
     for (auto &sd : c->side) {
         if ((e = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         if ((e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
@@ -298,7 +299,7 @@ const char *pce_kernel_name(int id)
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
-        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw"};
+        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -45,11 +45,12 @@ struct pce_ctx {
     // forked from `stream` onto one of these and joined back by whoever consumes its results:
     //   SIDE_TAIL  path finder + median of the pitch analysis (latency bound, ~0.4 ms with few CUs busy)
     //   SIDE_LUFS  the LUFS chain (sequential IIR per lane: few waves, long dependent chains)
-    // (the STFT passes were tried on a third one, launched beside the pitch kernels: both are VALU bound and the step
-    //  got slower, 3.33 -> 3.54 ms; they stay on `stream`, where they overlap the pitch tail)
-    enum { SIDE_TAIL = 0, SIDE_LUFS = 1, SIDE_COUNT = 2 };
+    //   SIDE_STFT  the HBM-bound normalisation pass of the STFT-dB (the FFT pass itself stays on `stream`: launched
+    //              beside the pitch kernels it only competed for VALU issue, 3.33 -> 3.54 ms)
+    enum { SIDE_TAIL = 0, SIDE_LUFS = 1, SIDE_STFT = 2, SIDE_COUNT = 3 };
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; } side[SIDE_COUNT];
     bool no_side = false;                // PCE_NO_AUX at pce_create: everything on `stream`
+    bool stft_two_fft = false;           // PCE_STFT_TWO_FFT at pce_create: traffic-minimal STFT-dB (the FFT runs twice)
     std::string err;
     int cu_count = 0;
 

@@ -226,6 +226,74 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_db(const int16_t *__restric
         for (int k = r0; k < NBINS; k += ROWS_PER_IT) o[(int64_t)k * cl.n_frames + fr] = tile[k][fr];
 }
 
+// Single-FFT form: k_stft_raw writes 10 log10(max(amin^2, |X|^2)) for every bin and reduces max |X| per clip in the same
+// pass; k_stft_norm then subtracts the clip's reference level and applies the -top_db floor in place (the same two
+// float operations, in the same order, that k_stft_db applies before its store: identical output bits).  The second
+// pass re-reads and re-writes the matrix (2 x 411 MB for the C2 batch), i.e. it trades HBM traffic for the second FFT:
+// the FFT passes are VALU bound (0.27-0.34 ms each) while the normalisation is HBM bound and runs on a side stream
+// beside the fp64 pitch kernels of the next batch, so the step gets shorter by one FFT pass.
+template <int F, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_stft_raw(const int16_t *__restrict__ pcm, const StClip *__restrict__ clips,
+                                                         const StTile *__restrict__ tiles, int n_tiles, int hop,
+                                                         const float *__restrict__ window, const float2 *__restrict__ g512,
+                                                         const float2 *__restrict__ g1024, unsigned int *__restrict__ clip_max,
+                                                         float amin2, float *__restrict__ out)
+{
+    __shared__ float2 zbuf[WAVES][ZBUF];
+    __shared__ float tile[NBINS][F + 1];
+    __shared__ float red[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bid = remap_xcd((int)blockIdx.x, (int)gridDim.x);
+    if (bid >= n_tiles) return;
+    StConst C; load_const(C, window, g512, g1024, lane);
+    const StTile tl = tiles[bid];
+    const StClip cl = clips[tl.clip];
+    const int nfr = min(F, cl.n_frames - tl.frame0);
+    float m = 0.f;
+    for (int fr = wv; fr < nfr; fr += WAVES) {
+        stft_frame<false>(pcm, cl, tl.frame0 + fr, hop, C, zbuf[wv], lane, [&](int k, float mag) {
+            m = fmaxf(m, mag);
+            const float pw = mag * mag;
+            tile[k][fr] = 10.0f * __log10f(fmaxf(amin2, pw));
+        });
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float r = 0.f;
+        for (int i = 0; i < WAVES; i++) r = fmaxf(r, red[i]);
+        atomicMax(clip_max + tl.clip, __float_as_uint(r));          // non-negative floats order as their bit patterns
+    }
+    float *o = out + cl.out_off + tl.frame0;
+    constexpr int ROWS_PER_IT = 64 * WAVES / F;
+    const int fr = tid % F, r0 = tid / F;
+    if (fr < nfr)
+        for (int k = r0; k < NBINS; k += ROWS_PER_IT) o[(int64_t)k * cl.n_frames + fr] = tile[k][fr];
+}
+
+__global__ __launch_bounds__(256) void k_stft_norm(const StClip *__restrict__ clips, const unsigned int *__restrict__ clip_max,
+                                                  float amin2, float top_db, float *__restrict__ out)
+{
+    const StClip cl = clips[blockIdx.y];
+    const float ref = __uint_as_float(clip_max[blockIdx.y]);
+    const float ref_db = 10.0f * log10f(fmaxf(amin2, ref * ref));
+    const float floor_db = 0.0f - top_db;
+    float *o = out + cl.out_off;
+    const int64_t count = (int64_t)NBINS * cl.n_frames;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += 4 * stride) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int64_t j = i + q * stride; v[q] = j < count ? o[j] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t j = i + q * stride;
+            if (j < count) { float db = v[q]; db -= ref_db; o[j] = fmaxf(db, floor_db); }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -237,6 +305,7 @@ int pce_stft_db_run(pce_ctx *c, int32_t n_fft, int32_t hop)
     if (n_fft != NFFT) return pce_fail(c, PCE_E_LIMIT, "n_fft %d unsupported (the engine implements the reference's n_fft=1024)", n_fft);
     if (hop <= 0 || hop > NFFT) return pce_fail(c, PCE_E_INVALID, "bad hop %d", hop);
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }       // the previous run's normalisation still owns the output
     constexpr int F = 16, WAVES = 4;
     if (c->st_nfft != n_fft || c->st_hop != hop) {
         const int32_t n = c->n_clips;
@@ -283,16 +352,33 @@ int pce_stft_db_run(pce_ctx *c, int32_t n_fft, int32_t hop)
     const float2 *g512 = c->st_twiddle.as<float2>();
     const float2 *g1024 = g512 + MC;
     PCE_HIP(c, hipMemsetAsync(c->st_max.p, 0, sizeof(unsigned int) * (size_t)c->n_clips, c->stream));
-    {
-        KernelTimer t(c, PCE_K_STFT_MAX);
-        hipLaunchKernelGGL((k_stft_max<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
-                           c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>());
-    }
-    {
-        KernelTimer t(c, PCE_K_STFT_DB);
-        hipLaunchKernelGGL((k_stft_db<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
-                           c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>(),
-                           1e-10f, 80.0f, c->st_out.as<float>());
+    if (c->stft_two_fft) {                                                           // traffic-minimal form: run the FFT twice
+        {
+            KernelTimer t(c, PCE_K_STFT_MAX);
+            hipLaunchKernelGGL((k_stft_max<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
+                               c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>());
+        }
+        {
+            KernelTimer t(c, PCE_K_STFT_DB);
+            hipLaunchKernelGGL((k_stft_db<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
+                               c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>(),
+                               1e-10f, 80.0f, c->st_out.as<float>());
+        }
+    } else {
+        {
+            KernelTimer t(c, PCE_K_STFT_DB);
+            hipLaunchKernelGGL((k_stft_raw<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
+                               c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>(),
+                               1e-10f, c->st_out.as<float>());
+        }
+        hipStream_t ss = c->stream;
+        { int rc = pce_side_begin(c, pce_ctx::SIDE_STFT, &ss); if (rc) return rc; }
+        if (c->n_clips > 0) {
+            KernelTimer t(c, PCE_K_STFT_NORM, ss);
+            hipLaunchKernelGGL(k_stft_norm, dim3(64, (unsigned)c->n_clips), dim3(256), 0, ss, c->st_off.as<StClip>(), c->st_max.as<unsigned int>(),
+                               1e-10f, 80.0f, c->st_out.as<float>());
+        }
+        { int rc = pce_side_end(c, pce_ctx::SIDE_STFT, ss); if (rc) return rc; }
     }
     PCE_HIP(c, hipGetLastError());
     c->st_ran = true;
@@ -315,6 +401,7 @@ int pce_stft_db_fetch(pce_ctx *c, int32_t clip, float *out)
     if (!c->st_nfft || !c->st_ran) return pce_fail(c, PCE_E_STATE, "pce_stft_db_fetch before pce_stft_db_run");
     if (clip < 0 || clip >= c->n_clips) return pce_fail(c, PCE_E_INVALID, "clip out of range");
     PCE_HIP(c, hipSetDevice(c->device));
+    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }
     const int64_t off = c->st_off_host[(size_t)clip], cnt = c->st_off_host[(size_t)clip + 1] - off;
     PCE_HIP(c, hipMemcpyAsync(out, c->st_out.as<float>() + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
@@ -326,6 +413,7 @@ int pce_stft_db_device(pce_ctx *c, const void **d_ptr, int64_t *bytes)
 {
     if (!c) return PCE_E_INVALID;
     if (!c->st_nfft || !c->st_ran) return pce_fail(c, PCE_E_STATE, "pce_stft_db_device before pce_stft_db_run");
+    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }   // work queued on the context's stream after this call sees the final values
     if (d_ptr) *d_ptr = c->st_out.p;
     if (bytes) *bytes = (int64_t)sizeof(float) * c->st_off_host[(size_t)c->n_clips];
     return PCE_OK;

@@ -192,3 +192,19 @@ def test_side_streams_do_not_change_results(engine, synth16k, monkeypatch):
         ref = run(single)
     monkeypatch.delenv("PCE_NO_AUX")
     assert run(engine) == ref
+
+
+@pytest.mark.gpu
+def test_stft_one_fft_and_two_fft_forms_agree_bitwise(engine, synth16k, monkeypatch):
+    """Default: one FFT pass writing unnormalised dB + an in-place normalisation pass on a side stream.
+    PCE_STFT_TWO_FFT=1: maximum pass, then the dB pass (each byte moved once).  Same float operations in the
+    same order on every bin: the matrices must be identical."""
+    clips = synth16k
+    monkeypatch.setenv("PCE_STFT_TWO_FFT", "1")
+    with pkg.ProsodyEngine(0) as two:
+        two.upload(clips, 16000); two.stft_db_run(1024, 256)
+        ref = [two.stft_db_fetch(i).tobytes() for i in range(len(clips))]
+    monkeypatch.delenv("PCE_STFT_TWO_FFT")
+    engine.upload(clips, 16000)
+    engine.stft_db_run(1024, 256); engine.stft_db_run(1024, 256)        # a second run queued behind the first one's side-stream pass
+    assert [engine.stft_db_fetch(i).tobytes() for i in range(len(clips))] == ref
