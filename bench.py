@@ -34,7 +34,10 @@ def load_pmc_traffic():
     path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["bytes_per_launch"]
+            t = json.load(f)["bytes_per_launch"]
+        if "k_stft_raw" in t and "k_stft_db" not in t:      # the dB pass is timed as `k_stft_db` whichever kernel implements it
+            t["k_stft_db"] = t["k_stft_raw"]
+        return t
     except Exception:
         return None
 
