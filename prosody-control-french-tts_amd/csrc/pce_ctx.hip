@@ -115,6 +115,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     }
     c->no_side = getenv("PCE_NO_AUX") != nullptr;
     c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
+    c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
     for (auto &sd : c->side) {
         if ((e = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         if ((e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }

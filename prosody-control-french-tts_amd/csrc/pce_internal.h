@@ -50,6 +50,7 @@ struct pce_ctx {
     enum { SIDE_TAIL = 0, SIDE_LUFS = 1, SIDE_STFT = 2, SIDE_COUNT = 3 };
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; } side[SIDE_COUNT];
     bool no_side = false;                // PCE_NO_AUX at pce_create: everything on `stream`
+    bool generic_median = false;         // PCE_ALIGN_GENERIC_MEDIAN at pce_create: the insertion-sort median filter for every width
     bool stft_two_fft = false;           // PCE_STFT_TWO_FFT at pce_create: traffic-minimal STFT-dB (the FFT runs twice)
     std::string err;
     int cu_count = 0;

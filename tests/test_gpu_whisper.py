@@ -108,3 +108,37 @@ def test_forced_alignment_matches_torch(engine, clips):
         jumps_g = got["time_indices"][np.r_[True, np.diff(got["text_indices"]) > 0]]
         jumps_w = tj[np.r_[True, np.diff(ti) > 0]]
         assert len(jumps_g) == len(jumps_w) and np.mean(np.abs(jumps_g - jumps_w) <= 1) >= 0.95          # observed: identical
+
+
+def test_median_filter_network_equals_generic_sort(engine, clips, monkeypatch):
+    """Width 7 (the default) selects its median with a 13-exchange network in registers; a context created with
+    PCE_ALIGN_GENERIC_MEDIAN=1 runs the insertion sort used for every other width.  A median is a selection: the
+    cost matrices must be bit-identical.  Width 5 goes through the generic path and is checked against torch."""
+    from prosody_control_french_tts_amd import ProsodyEngine
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=4)
+    We, Wd = WW.synthetic_weights(edims), WW.synthetic_decoder_weights(tdims)
+    use = clips[:2]
+    rng = np.random.default_rng(5)
+    toks = [rng.integers(0, 300, size=n).tolist() for n in (20, 41)]
+    num_frames = [len(c) // 160 for c in use]
+
+    def run(eng, width):
+        eng.upload(use, 16000); eng.logmel_run(80)
+        eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
+        eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+        return eng.whisper_align(toks, num_frames, 3, medfilt_width=width, want_cost=True)
+
+    monkeypatch.setenv("PCE_ALIGN_GENERIC_MEDIAN", "1")
+    with ProsodyEngine(0) as generic:
+        ref = run(generic, 7)
+    monkeypatch.delenv("PCE_ALIGN_GENERIC_MEDIAN")
+    got = run(engine, 7)
+    for g, r in zip(got, ref):
+        assert g["cost"].tobytes() == r["cost"].tobytes()
+        assert np.array_equal(g["time_indices"], r["time_indices"])
+    got5 = run(engine, 5)
+    for i in range(2):
+        enc = engine.whisper_encode_fetch(i)
+        cost, _, _ = WO.find_alignment(toks[i], enc, Wd, tdims, num_frames[i], 3, medfilt_width=5)
+        assert np.linalg.norm(got5[i]["cost"] - cost) / np.linalg.norm(cost) <= 3e-2
