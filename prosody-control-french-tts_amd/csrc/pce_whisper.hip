@@ -402,7 +402,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
 // 24 KB stages so that two workgroups still share a CU, and the output leaves through the same 128 x 128 LDS tile
 // in two column passes.
 // ---------------------------------------------------------------------------
-constexpr int W_BN = 256, W_BK = 32;
+constexpr int W_BN = 256, W_BK = 32, W_STAGES = 2;   // a third stage (72 KB, still two workgroups per CU) measured +0.2 %: not latency bound
 constexpr int W_STAGE = (G_BM + W_BN) * W_BK;                   // bf16 elements per stage (24 KB)
 __device__ __forceinline__ int swz32(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }   // 64-byte rows (see swz_chunk)
 // ROWS x 32 k operand tile: wave-instructions of 1 KiB (16 rows each)
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_wide(const bf16 *__restri
                                                         const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
                                                         const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles)
 {
-    constexpr int SMEM_ELEMS = (2 * W_STAGE * 2 > G_BM * G_TLD * 4 ? 2 * W_STAGE : G_BM * G_TLD * 2);
+    constexpr int SMEM_ELEMS = (W_STAGES * W_STAGE * 2 > G_BM * G_TLD * 4 ? W_STAGES * W_STAGE : G_BM * G_TLD * 2);
     __shared__ __attribute__((aligned(1024))) bf16 smem[SMEM_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 2, wc = wv & 3;                         // 2 x 4 waves, 64 x 64 each
@@ -454,16 +454,25 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_wide(const bf16 *__restri
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / W_BK;
-    stage_rows32<G_BM>(A, lda, m0, M - 1, 0, smem, wv, lane);
-    stage_rows32<W_BN>(B, K, n0, N - 1, 0, smem + G_BM * W_BK, wv, lane);
+    // the bias loads above are older than every DMA: a counted wait on the DMAs retires them too
+#pragma unroll
+    for (int s = 0; s < W_STAGES - 1; s++)
+        if (s < nk) {
+            stage_rows32<G_BM>(A, lda, m0, M - 1, s * W_BK, smem + s * W_STAGE, wv, lane);
+            stage_rows32<W_BN>(B, K, n0, N - 1, s * W_BK, smem + s * W_STAGE + G_BM * W_BK, wv, lane);
+        }
+    int cur = 0;
     for (int kt = 0; kt < nk; kt++) {
-        const bf16 *sA = smem + (kt & 1) * W_STAGE, *sB = sA + G_BM * W_BK;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bf16 *sA = smem + cur * W_STAGE, *sB = sA + G_BM * W_BK;
+        // K-step kt has landed once at most the DMAs of the one younger stage (3 per wave) are outstanding
+        if (W_STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) {
-            bf16 *nA = smem + ((kt + 1) & 1) * W_STAGE;
-            stage_rows32<G_BM>(A, lda, m0, M - 1, (kt + 1) * W_BK, nA, wv, lane);
-            stage_rows32<W_BN>(B, K, n0, N - 1, (kt + 1) * W_BK, nA + G_BM * W_BK, wv, lane);
+        if (kt + W_STAGES - 1 < nk) {                            // refill the stage K-step kt-1 has released
+            int nx = cur + W_STAGES - 1; if (nx >= W_STAGES) nx -= W_STAGES;
+            bf16 *nA = smem + nx * W_STAGE;
+            stage_rows32<G_BM>(A, lda, m0, M - 1, (kt + W_STAGES - 1) * W_BK, nA, wv, lane);
+            stage_rows32<W_BN>(B, K, n0, N - 1, (kt + W_STAGES - 1) * W_BK, nA + G_BM * W_BK, wv, lane);
         }
         bf16x8 a[4], b[4];
 #pragma unroll
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_wide(const bf16 *__restri
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        cur = cur + 1 == W_STAGES ? 0 : cur + 1;
     }
     float *tile = reinterpret_cast<float *>(smem);               // [128][G_TLD] fp32: one half of the columns per pass
 #pragma unroll

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -27,8 +28,10 @@ __device__ __forceinline__ void stage_rows32(const bf16 *__restrict__ G, int64_t
 }
 // ABL bit 0: skip MFMA; bit 1: skip ds_reads (fragments loaded once); bit 2: skip global loads after the prologue; bit 3: skip the epilogue store
 template <int ABL>
-__global__ __launch_bounds__(THREADS, 4) void k_wide(const bf16 *__restrict__ A, const bf16 *__restrict__ B, int M, int N, int K, bf16 *__restrict__ C, int sn_tiles, int sm_tiles)
+__global__ __launch_bounds__(THREADS, 4) void k_wide(const bf16 *__restrict__ A, const bf16 *__restrict__ B, int M, int N, int K, bf16 *__restrict__ C, int sn_tiles, int sm_tiles, unsigned long long *stamps = nullptr)
 {
+    unsigned long long st0 = 0, sr0 = 0;
+    if (stamps) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int SMEM_ELEMS = (2 * STAGE * 2 > BM * TLD * 4 ? 2 * STAGE : BM * TLD * 2);
     __shared__ __attribute__((aligned(1024))) bf16 smem[SMEM_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_wide(const bf16 *__restrict__ A,
                 __builtin_nontemporal_store(o, reinterpret_cast<bf16x8 *>(C + (int64_t)(m0 + row) * N + n0 + p * 128 + cx));
         }
     }
+    if (stamps && threadIdx.x == 0) { unsigned long long *o = stamps + 4 * (blockIdx.y * gridDim.x + blockIdx.x); o[0] = st0; o[1] = sr0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 #include "gemm_lab_v2.inc"
@@ -150,6 +154,29 @@ int main(int argc, char **argv)
 #define RUN(ABL) { float ms = time_ms([&] { hipLaunchKernelGGL((k_wide<ABL>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm); }, 5); \
                    printf("wide abl %2d: %.3f ms  %.0f TFLOP/s\n", ABL, ms, tf / ms); }
     RUN(0)
+    {
+        unsigned long long *stamps; const size_t nb = (size_t)grid.x * grid.y;
+        CK(hipMalloc(&stamps, nb * 32));
+        auto clock_of = [&](const char *name, auto launch) {
+            for (int i = 0; i < 400; i++) launch();
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(nb * 4);
+            CK(hipMemcpy(h.data(), stamps, nb * 32, hipMemcpyDeviceToHost));
+            std::vector<double> f;
+            for (size_t b = 0; b < nb; b++) if (h[4 * b + 3] > h[4 * b + 1]) f.push_back((double)(h[4 * b + 2] - h[4 * b]) / (double)(h[4 * b + 3] - h[4 * b + 1]) * 100.0);
+            std::sort(f.begin(), f.end());
+            printf("in-kernel clock, %s: median %.0f MHz (p10 %.0f, p90 %.0f) over %zu workgroups\n", name, f[f.size() / 2], f[f.size() / 10], f[f.size() * 9 / 10], f.size());
+        };
+        clock_of("wide full", [&] { hipLaunchKernelGGL((k_wide<0>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm, stamps); });
+        clock_of("wide no-MFMA (loads, reads, stores)", [&] { hipLaunchKernelGGL((k_wide<1>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm, stamps); });
+        clock_of("wide MFMA only", [&] { hipLaunchKernelGGL((k_wide<14>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm, stamps); });
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_wide<0>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm); }, 50);
+        printf("wide full after 1 s of load: %.3f ms  %.0f TFLOP/s\n", ms, tf / ms);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wide<14>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm); }, 50);
+        printf("wide MFMA only, sustained: %.3f ms  %.0f TFLOP/s\n", ms, tf / ms);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_wide<11>), grid, dim3(THREADS), 0, 0, A, B, M, N, K, C, wsn, wsm); }, 50);
+        printf("wide loads only, sustained: %.3f ms\n", ms);
+    }
     run_v2(A, B, C, C2, M, N, K, tf);
     return 0;
 }
