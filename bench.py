@@ -123,7 +123,8 @@ def main():
     clips = synth.synth_batch(args.clips, args.seconds, rate, first=rank * args.clips)
     # CPU baseline first: its all-cores leg forks worker processes, which must happen before this process
     # initialises the GPU
-    cpu = cpu_baseline(clips, rate, args.cpu_clips) if (rank == 0 and args.cpu_clips > 0) else None
+    # (rank 0 of a single-GPU run only: the multi-GPU lines carry "cpu_baseline": null)
+    cpu = cpu_baseline(clips, rate, args.cpu_clips) if (world == 1 and rank == 0 and args.cpu_clips > 0) else None
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
