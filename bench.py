@@ -56,6 +56,28 @@ def _cpu_one(args):
     return len(c)
 
 
+def _cpu_one_reference_shaped(args):
+    """The same arithmetic called the way the reference calls it: every measurement takes a PATH and decodes the
+    file again (Code/audioPipeline.py:319,327,340,360; Code/Aligners/use_whisper_timestamped.py:130,199,583)."""
+    path, rate = args
+    import wave
+    from oracle import oracle as O
+
+    def decode():
+        with wave.open(path, "rb") as w:
+            return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+
+    O.gate_check(decode()); O.gate_check(decode())                  # the noise gate runs twice per file
+    O.rms_db_int16_wrapped(decode())
+    O.lufs_c(decode().astype(np.float64), rate)
+    n = len(decode())                                                # get_duration
+    f0 = O.pitch_ac(decode().astype(np.float64) / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+    v = f0[f0 > 0]
+    _ = float(np.median(v)) if v.size else 0.0
+    O.stft_db(decode().astype(np.float32) / 32768.0)
+    return n
+
+
 def load_pmc_valu(kernel):
     """Mean SQ_INSTS_VALU per launch of `kernel` from the committed rocprofv3 --pmc pass of this command."""
     import csv
@@ -93,6 +115,26 @@ def cpu_baseline(clips, rate, budget_clips):
         out["all_cores"] = {"value": secs / dtp, "processes": workers, "host_cores": os.cpu_count(), "seconds": dtp}
     except Exception as e:                                         # the single-thread figure is the contract's
         out["all_cores"] = {"error": str(e)}
+    try:
+        # reference-shaped: paths in, seven decodes per file (SURVEY.md section 8d iii), one thread, 32 clips
+        import tempfile
+        import wave
+        sub = sample[:32]
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for i, c in enumerate(sub):
+                pth = os.path.join(td, f"clip{i}.wav")
+                with wave.open(pth, "wb") as w:
+                    w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate); w.writeframes(c.astype("<i2").tobytes())
+                paths.append(pth)
+            t0 = time.perf_counter()
+            for pth in paths:
+                _cpu_one_reference_shaped((pth, rate))
+            dtr = time.perf_counter() - t0
+        out["reference_shaped"] = {"value": sum(len(c) for c in sub) / rate / dtr, "clips": len(sub), "decodes_per_file": 7, "cores": 1,
+                                   "seconds": dtr}
+    except Exception as e:
+        out["reference_shaped"] = {"error": str(e)}
     return out
 
 
