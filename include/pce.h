@@ -94,6 +94,18 @@ int pce_resample_run(pce_ctx *ctx, int32_t up, int32_t down, const double *taps,
 /* copy the resident batch back: pcm may be NULL to query offsets[n_clips+1] / sample_rate only */
 int pce_download_pcm_s16(pce_ctx *ctx, int16_t *pcm, int64_t *offsets, int32_t *sample_rate);
 
+/* ---- frame-level short-time energy (the energy detector of the aligner's VAD) ----
+ * Replaces the per-window energy of auditok.split(energy_threshold=50), which whisper-timestamped runs because the
+ * aligner asks for `"vad": "auditok"` (Code/Aligners/use_whisper_timestamped.py:152; packages absent from
+ * /root/reference: restated from their published behaviour, parity unpinned).  Frame k of a clip of n samples covers
+ * [k*hop, min(k*hop + window, n)), k = 0 .. ceil(n/hop)-1: with hop == window these are auditok's analysis windows
+ * (0.05 s; the last one short).  sum_sq[k] = exact integer sum of squares, count[k] = samples in the frame; the
+ * mean / sqrt / 20 log10 / threshold are host logic (Aligners/vad.py).  requantize != 0 first applies, per sample,
+ * whisper-timestamped's float32 round trip: (int16)((float32)(x / 32768) * 32767), truncated toward zero. */
+int pce_frame_energy_run(pce_ctx *ctx, int32_t window, int32_t hop, int32_t requantize);
+int pce_frame_energy_shape(pce_ctx *ctx, int32_t clip, int64_t *n_frames);
+int pce_frame_energy_fetch(pce_ctx *ctx, int32_t clip, int64_t *sum_sq /* [n_frames] or NULL */, int32_t *count /* [n_frames] or NULL */);
+
 /* ---- R3 / R7: short-time energy, peak, silence gate --------------------
  * Replaces _calculate_loudness (Code/Pipeline/compute_loudness_adjustments.py:8-25),
  * _check_audio_content (Code/Aligners/use_whisper_timestamped.py:197-229 and its
@@ -256,7 +268,7 @@ enum pce_kernel_id {
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
     PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN, PCE_K_NW, PCE_K_STFT_NORM,
-    PCE_K_COUNT
+    PCE_K_FRAME_ENERGY, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

@@ -16,7 +16,9 @@ Parity status per function (see DESIGN.md "Oracle"):
   not installable here; restated from the published algorithm, checked by
   analytic known-answer tests): ``pitch_ac`` (Praat, praat-parselmouth==0.4.5),
   ``lufs`` (pyloudnorm, unpinned in tts-env.yml), ``pydub_slice`` (pydub==0.25.1),
-  ``stft_db`` (librosa==0.11.0), ``log_mel`` (openai-whisper==20240930).
+  ``stft_db`` (librosa==0.11.0), ``log_mel`` (openai-whisper==20240930),
+  ``frame_energy`` / ``frame_energy_db`` (auditok==0.3.0 energy validator behind
+  whisper-timestamped==1.15.8 ``get_vad_segments(method="auditok")``).
 """
 from __future__ import annotations
 
@@ -405,3 +407,38 @@ def resample_int16(pcm_i16: np.ndarray, rate_in: int, rate_out: int) -> np.ndarr
     g = math.gcd(rate_in, rate_out)
     y = scipy.signal.resample_poly(np.asarray(pcm_i16, dtype=np.float64), rate_out // g, rate_in // g)
     return np.clip(np.rint(y), -32768, 32767).astype(np.int16)
+
+
+# ---------------------------------------------------------------- energy VAD front end (3P, parity unpinned)
+def frame_energy(pcm_i16: np.ndarray, window: int, hop: int = None, requantize: bool = False):
+    """Per analysis window: (exact integer sum of squares, samples in the window).
+
+    Follows the call chain behind ``"vad": "auditok"`` (Code/Aligners/use_whisper_timestamped.py:152):
+    whisper.load_audio leaves int16 / 32768 as float32; whisper-timestamped's ``get_vad_segments`` feeds auditok
+    ``(audio * 32767).astype(np.int16)`` (``requantize``); auditok reads blocks of ``int(0.05 * rate)`` samples,
+    the last one short.  Frame k = [k*hop, min(k*hop + window, n)), k < ceil(n / hop)."""
+    x = np.asarray(pcm_i16, dtype=np.int16)
+    if requantize:
+        a = x.astype(np.float32) / np.float32(32768.0)
+        x = (a * 32767).astype(np.int16)
+    hop = window if hop is None else hop
+    n = len(x)
+    nf = -(-n // hop)
+    ss = np.zeros(nf, dtype=np.int64); cnt = np.zeros(nf, dtype=np.int32)
+    for k in range(nf):
+        seg = x[k * hop:k * hop + window].astype(np.int64)
+        ss[k] = int(np.sum(seg * seg)); cnt[k] = len(seg)
+    return ss, cnt
+
+
+def frame_energy_db(pcm_i16: np.ndarray, window: int, requantize: bool = False) -> np.ndarray:
+    """auditok's window energy: 20 log10(max(sqrt(mean(x^2)), 1e-10)) on float64 samples."""
+    x = np.asarray(pcm_i16, dtype=np.int16)
+    if requantize:
+        x = ((x.astype(np.float32) / np.float32(32768.0)) * 32767).astype(np.int16)
+    out = []
+    for k in range(-(-len(x) // window)):
+        seg = x[k * window:(k + 1) * window].astype(np.float64)
+        out.append(20.0 * np.log10(max(np.sqrt(np.mean(seg ** 2)), 1e-10)))
+    return np.array(out)
+

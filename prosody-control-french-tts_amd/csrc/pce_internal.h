@@ -99,6 +99,11 @@ struct pce_ctx {
     std::vector<int64_t> st_off_host;   // float offsets per clip (n_clips+1)
     std::vector<int32_t> st_frames;
 
+    // frame energy (analysis windows of the energy VAD)
+    DevBuf fr_doff, fr_sum, fr_cnt;
+    std::vector<int64_t> fr_off;        // frames before clip i (n_clips+1)
+    bool fr_ran = false;
+
     // whisper (opaque: defined in pce_whisper.hip)
     void *whisper = nullptr;
 

@@ -81,12 +81,13 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
            "pce_upload_pcm_s16", "pce_bind_pcm_s16_device", "pce_num_clips",
            "pce_energy_run", "pce_energy_fetch", "pce_lufs_run", "pce_lufs_fetch",
+           "pce_frame_energy_run", "pce_frame_energy_shape", "pce_frame_energy_fetch",
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
@@ -114,6 +115,9 @@ def load_library() -> C.CDLL:
     lib.pce_energy_run.argtypes = [vp, vp, i32, i32]
     lib.pce_energy_fetch.argtypes = [vp, vp]
     lib.pce_lufs_run.argtypes = [vp, vp, i32]
+    lib.pce_frame_energy_run.argtypes = [vp, i32, i32, i32]
+    lib.pce_frame_energy_shape.argtypes = [vp, i32, C.POINTER(i64)]
+    lib.pce_frame_energy_fetch.argtypes = [vp, i32, vp, vp]
     lib.pce_lufs_fetch.argtypes = [vp, vp, vp]
     lib.pce_pitch_plan.argtypes = [vp, C.POINTER(PitchParams), vp, i32, vp, vp]
     lib.pce_pitch_run.argtypes = [vp, C.POINTER(PitchParams), vp, i32]
@@ -413,6 +417,19 @@ class ProsodyEngine:
         pi = np.zeros((b, n + m), dtype=np.int32); pj = np.zeros((b, n + m), dtype=np.int32); pl = np.zeros(b, dtype=np.int32)
         self._check(self._lib.pce_dtw(self._ctx, x.ctypes.data, n, m, b, pi.ctypes.data, pj.ctypes.data, pl.ctypes.data))
         return [(pi[k, :pl[k]].copy(), pj[k, :pl[k]].copy()) for k in range(b)]
+
+    def frame_energy_run(self, window: int, hop: int = None, requantize: bool = False):
+        """Exact integer energy of every analysis window of every clip (k_frame_energy): frame k covers
+        [k*hop, min(k*hop + window, n)); hop defaults to window (auditok's blocks)."""
+        self._check(self._lib.pce_frame_energy_run(self._ctx, int(window), int(window if hop is None else hop), 1 if requantize else 0))
+
+    def frame_energy_fetch(self, clip: int):
+        """-> (sum_sq int64[n_frames], count int32[n_frames]) of one clip."""
+        nf = C.c_int64()
+        self._check(self._lib.pce_frame_energy_shape(self._ctx, int(clip), C.byref(nf)))
+        ss = np.zeros(nf.value, dtype=np.int64); cnt = np.zeros(nf.value, dtype=np.int32)
+        self._check(self._lib.pce_frame_energy_fetch(self._ctx, int(clip), ss.ctypes.data, cnt.ctypes.data))
+        return ss, cnt
 
     def nw_align(self, pairs, match=1, mismatch=-1, gap=-1):
         """Batched Needleman-Wunsch over integer token ids: ``pairs`` = [(ids_a, ids_b), ...] ->
