@@ -169,7 +169,10 @@ int pce_stats_enqueue(pce_ctx *c, int32_t slot)
 {
     if (!c || slot < 0 || slot > 1) return PCE_E_INVALID;
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_join_aux(c); if (rc) return rc; }           // the pitch summaries come from the auxiliary stream
+    // the statistics come from the pitch tail and the LUFS chain; the STFT normalisation pass (SIDE_STFT) is left running:
+    // joining it here put its 0.12 ms at the end of every step, in front of the next batch's kernels
+    { int rc = pce_side_join(c, pce_ctx::SIDE_TAIL); if (rc) return rc; }
+    { int rc = pce_side_join(c, pce_ctx::SIDE_LUFS); if (rc) return rc; }
     pce_ctx::StatSlot &st = c->stat[slot];
     const size_t b_en = pce_energy_stage_bytes(c), b_lu = c->lu_n > 0 ? sizeof(double) * (size_t)c->lu_n : 0, b_pi = pce_pitch_stage_bytes(c);
     auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };

@@ -1504,10 +1504,15 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
     hipStream_t tail = c->stream;
     const int64_t total = c->pi_total_frames;
     if (total > 0) {
-        int rc = pce_energy_launch(c, n, 500, c->pi_n_energy_work, c->pi_peakwork, c->pi_acc);
-        if (rc) return rc;
+        // the slice sums and extrema (Praat's mean subtraction and global peak): when pce_energy_run has just produced them
+        // for this very slice list they are read from its accumulators (stream ordered) instead of streaming the batch again
+        const bool reuse = c->en_n == n && c->en_cache.same(slices, n);
+        if (!reuse) {
+            int rc = pce_energy_launch(c, n, 500, c->pi_n_energy_work, c->pi_peakwork, c->pi_acc);
+            if (rc) return rc;
+        }
         size_t stride; const long long *a_sum; const int *a_hi, *a_lo;
-        pce_energy_range_ptrs(c->pi_acc, &stride, &a_sum, &a_hi, &a_lo);
+        pce_energy_range_ptrs(reuse ? c->en_out : c->pi_acc, &stride, &a_sum, &a_hi, &a_lo);
         double *intensity = c->pi_gpeak.as<double>();
         int *ncand = reinterpret_cast<int *>(intensity + (total + 1));
         {

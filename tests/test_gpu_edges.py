@@ -208,3 +208,28 @@ def test_stft_one_fft_and_two_fft_forms_agree_bitwise(engine, synth16k, monkeypa
     engine.upload(clips, 16000)
     engine.stft_db_run(1024, 256); engine.stft_db_run(1024, 256)        # a second run queued behind the first one's side-stream pass
     assert [engine.stft_db_fetch(i).tobytes() for i in range(len(clips))] == ref
+
+
+@pytest.mark.gpu
+def test_pitch_reuses_the_energy_pass_only_for_the_same_slices(engine, synth16k):
+    """pce_pitch_run reads the slice sums / extrema from pce_energy_run's accumulators when that call covered the very
+    same slice list (one stream over the batch saved); any other order or slice list takes its own pass.  Same bits."""
+    clips = synth16k
+    p = pkg.PitchParams.praat(150.0, 600.0)
+    engine.upload(clips, 16000)
+    sl = engine.whole_clip_slices()
+
+    def pitch():
+        engine.pitch_run(sl, p)
+        r = engine.pitch_fetch(want_f0=True, want_strength=True)
+        return r["f0"].tobytes(), r["strength"].tobytes(), r["summary"].tobytes()
+
+    alone = pitch()                                            # no energy pass before: own accumulators
+    engine.energy_run(sl, 500)
+    assert pitch() == alone                                    # reused
+    half = sl.copy(); half["end"] = half["end"] // 2
+    engine.energy_run(half, 500)
+    assert pitch() == alone                                    # different slice list in the energy pass: not reused
+    engine.energy_run(sl, 123)                                 # another gate threshold does not matter for sums / extrema
+    assert pitch() == alone
+    assert engine.energy_fetch()["sum_sq"].tolist() == [int((c.astype(np.int64) ** 2).sum()) for c in clips]
