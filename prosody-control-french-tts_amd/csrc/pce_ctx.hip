@@ -116,8 +116,14 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->no_side = getenv("PCE_NO_AUX") != nullptr;
     c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
-    for (auto &sd : c->side) {
-        if ((e = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    for (int si = 0; si < pce_ctx::SIDE_COUNT; si++) {
+        pce_ctx::Side &sd = c->side[si];
+        // the STFT normalisation pass streams 0.4 GB beside the next batch's first kernels and the statistics copies:
+        // lowest priority, so that those (small, latency critical) are dispatched first
+        const int prio = si == pce_ctx::SIDE_STFT ? prio_least : 0;     // (measured: 3.02 -> 3.00 ms per step)
+        if ((e = hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, prio)) != hipSuccess) { delete c; return fail("hipStreamCreate", e); }
         if ((e = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)) != hipSuccess) { delete c; return fail("hipEventCreate", e); }
     }
     return c;
@@ -148,6 +154,7 @@ void pce_destroy(pce_ctx *c)
     for (auto &st : c->stat) {
         if (st.host) (void)hipHostFree(st.host);
         if (st.ev) (void)hipEventDestroy(st.ev);
+        if (st.ev_main) (void)hipEventDestroy(st.ev_main);
     }
     pce_whisper_free(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -169,10 +176,6 @@ int pce_stats_enqueue(pce_ctx *c, int32_t slot)
 {
     if (!c || slot < 0 || slot > 1) return PCE_E_INVALID;
     PCE_HIP(c, hipSetDevice(c->device));
-    // the statistics come from the pitch tail and the LUFS chain; the STFT normalisation pass (SIDE_STFT) is left running:
-    // joining it here put its 0.12 ms at the end of every step, in front of the next batch's kernels
-    { int rc = pce_side_join(c, pce_ctx::SIDE_TAIL); if (rc) return rc; }
-    { int rc = pce_side_join(c, pce_ctx::SIDE_LUFS); if (rc) return rc; }
     pce_ctx::StatSlot &st = c->stat[slot];
     const size_t b_en = pce_energy_stage_bytes(c), b_lu = c->lu_n > 0 ? sizeof(double) * (size_t)c->lu_n : 0, b_pi = pce_pitch_stage_bytes(c);
     auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
@@ -186,16 +189,34 @@ int pce_stats_enqueue(pce_ctx *c, int32_t slot)
     char *base = static_cast<char *>(st.host);
     st.off_lu = up(b_en); st.off_pi = st.off_lu + up(b_lu);
     st.en_n = c->en_n; st.lu_n = c->lu_n; st.pi_n = c->pi_n;
+    // The LUFS values and the pitch summaries are copied on the side stream that produced them, right behind the producing
+    // kernel (enqueued on `stream` at the end of a step the same copies ran beside the STFT normalisation pass, up to 90 us
+    // each), and `stream` itself does NOT wait for them: the slot's event is recorded on the last stream to finish (the
+    // pitch tail) after it has waited for the other copies, so the next batch's first kernels start while the tail of
+    // this one is still running.  The side streams stay `pending`: whoever reuses their buffers joins them as before.
+    // The STFT pass (SIDE_STFT) is not involved: the statistics do not depend on it.
+    pce_ctx::Side &sl = c->side[pce_ctx::SIDE_LUFS], &stl = c->side[pce_ctx::SIDE_TAIL];
     if (c->en_n >= 0) { int rc = pce_energy_stage_enqueue(c, base, st.en_len); if (rc) return rc; }
-    if (c->lu_n > 0) PCE_HIP(c, hipMemcpyAsync(base + st.off_lu, c->lu_out.p, b_lu, hipMemcpyDeviceToHost, c->stream));
+    if (c->lu_n > 0) PCE_HIP(c, hipMemcpyAsync(base + st.off_lu, c->lu_out.p, b_lu, hipMemcpyDeviceToHost, sl.pending ? sl.s : c->stream));
+    if (sl.pending) PCE_HIP(c, hipEventRecord(sl.join, sl.s));                  // the join now covers the copy
     if (c->lu_n >= 0) st.lu_status = c->lu_host_status;
     if (c->pi_n >= 0) {
-        int rc = pce_pitch_stage_enqueue(c, base + st.off_pi); if (rc) return rc;
+        int rc = pce_pitch_stage_enqueue(c, base + st.off_pi, stl.pending ? stl.s : c->stream); if (rc) return rc;
         st.pi_frames.resize((size_t)c->pi_n);
         for (int32_t i = 0; i < c->pi_n; i++) st.pi_frames[(size_t)i] = c->pi_frame_off[(size_t)i + 1] - c->pi_frame_off[(size_t)i];
         st.pi_t1 = c->pi_t1; st.pi_status = c->pi_status;
     }
-    PCE_HIP(c, hipEventRecord(st.ev, c->stream));
+    if (stl.pending) {
+        if (!st.ev_main) PCE_HIP(c, hipEventCreateWithFlags(&st.ev_main, hipEventDisableTiming));
+        PCE_HIP(c, hipEventRecord(st.ev_main, c->stream));                     // behind the copies made on `stream`
+        PCE_HIP(c, hipStreamWaitEvent(stl.s, st.ev_main, 0));
+        if (sl.pending) PCE_HIP(c, hipStreamWaitEvent(stl.s, sl.join, 0));
+        PCE_HIP(c, hipEventRecord(st.ev, stl.s));
+        PCE_HIP(c, hipEventRecord(stl.join, stl.s));                           // later joins cover the copy and the waits
+    } else {
+        { int rc = pce_side_join(c, pce_ctx::SIDE_LUFS); if (rc) return rc; }
+        PCE_HIP(c, hipEventRecord(st.ev, c->stream));
+    }
     st.armed = true;
     return PCE_OK;
 }

@@ -109,7 +109,7 @@ struct pce_ctx {
 
     // asynchronous statistics fetch (pce_stats_enqueue / pce_stats_wait)
     struct StatSlot {
-        void *host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool armed = false;
+        void *host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr, ev_main = nullptr; bool armed = false;
         int32_t en_n = -1, lu_n = -1, pi_n = -1;
         size_t off_lu = 0, off_pi = 0;
         std::vector<int64_t> en_len, pi_frames;
@@ -151,7 +151,7 @@ size_t pce_energy_stage_bytes(const pce_ctx *c);
 int pce_energy_stage_enqueue(pce_ctx *c, void *pinned, std::vector<int64_t> &lens);
 void pce_energy_stage_unpack(const void *pinned, const std::vector<int64_t> &lens, pce_energy *out);
 size_t pce_pitch_stage_bytes(const pce_ctx *c);
-int pce_pitch_stage_enqueue(pce_ctx *c, void *pinned);
+int pce_pitch_stage_enqueue(pce_ctx *c, void *pinned, hipStream_t on = nullptr);
 void pce_pitch_stage_unpack(const void *pinned, int32_t n, pce_pitch_summary *out);
 
 // Host-side copy of the sizes Praat derives before its frame loop (see pce_pitch.hip).

@@ -1631,10 +1631,10 @@ int pce_pitch_fetch(pce_ctx *c, double *f0, double *strength, pce_pitch_summary 
 } // extern "C"
 
 size_t pce_pitch_stage_bytes(const pce_ctx *c) { return c->pi_n > 0 ? sizeof(PiSummaryDev) * (size_t)c->pi_n : 0; }
-int pce_pitch_stage_enqueue(pce_ctx *c, void *pinned)
+int pce_pitch_stage_enqueue(pce_ctx *c, void *pinned, hipStream_t on)
 {
     if (c->pi_n > 0)
-        PCE_HIP(c, hipMemcpyAsync(pinned, c->pi_summary.p, sizeof(PiSummaryDev) * (size_t)c->pi_n, hipMemcpyDeviceToHost, c->stream));
+        PCE_HIP(c, hipMemcpyAsync(pinned, c->pi_summary.p, sizeof(PiSummaryDev) * (size_t)c->pi_n, hipMemcpyDeviceToHost, on ? on : c->stream));
     return PCE_OK;
 }
 void pce_pitch_stage_unpack(const void *pinned, int32_t n, pce_pitch_summary *out)
