@@ -35,58 +35,87 @@ constexpr int ZBUF = MC + MC / 8;                           // 576 complex per w
 struct StTile { int32_t clip, frame0; };
 struct StClip { int64_t pcm_off, len, out_off; int32_t n_frames, pad; };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }     // a * (-i)
+// Complex values are register PAIRS and the arithmetic is packed fp32 (v_pk_add_f32 / v_pk_mul_f32: two lanes of a
+// pair per issue slot): the frame transform is VALU-issue bound (SQ_INSTS_VALU x 4 cycles = 2/3 of its duration), and
+// the packed form issues about half the instructions.  Multiplications by -i and conjugations ride on the packed
+// instructions' op_sel / neg modifiers (inline asm: the compiler materialises them as v_xor + v_mov).  Every
+// component sees exactly the operations, in the order, of the scalar formulation (mul and add separately rounded,
+// no FMA), so the results are bit-identical to it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b)        // a + (-i) b = (a.x + b.y, a.y - b.x)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ v2f sub_mi(v2f a, v2f b)        // a - (-i) b = (a.x - b.y, a.y + b.x)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b)      // a + conj(b) = (a.x + b.x, a.y - b.y)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b)      // a - conj(b) = (a.x - b.x, a.y + b.y)
+{
+    v2f r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ v2f cmul(v2f a, v2f w)          // (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
+{
+    v2f p, q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(w));      // (a.x w.x, a.x w.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(a), "v"(w));      // (a.y w.y, a.y w.x)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));                       // (p.x - q.x, p.y + q.y)
+    return r;
+}
 
 // forward 8-point DFT, in place: a[u] <- sum_t a[t] exp(-2 pi i t u / 8)
-__device__ __forceinline__ void dft8(float2 a[8])
+__device__ __forceinline__ void dft8(v2f a[8])
 {
     const float h = 0.70710678118654752440f;
-    float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
-    float2 b1 = cadd(a[1], a[5]), b5 = csub(a[1], a[5]);
-    float2 b2 = cadd(a[2], a[6]), b6 = csub(a[2], a[6]);
-    float2 b3 = cadd(a[3], a[7]), b7 = csub(a[3], a[7]);
-    b5 = make_float2((b5.x + b5.y) * h, (b5.y - b5.x) * h);       // * (1 - i)/sqrt2
-    b6 = mul_mi(b6);                                               // * -i
-    b7 = make_float2((b7.y - b7.x) * h, -(b7.x + b7.y) * h);      // * (-1 - i)/sqrt2
+    v2f b0 = a[0] + a[4], b4 = a[0] - a[4];
+    v2f b1 = a[1] + a[5], b5 = a[1] - a[5];
+    v2f b2 = a[2] + a[6], b6 = a[2] - a[6];
+    v2f b3 = a[3] + a[7], b7 = a[3] - a[7];
+    b5 = add_mi(b5, b5) * h;                                       // * (1 - i)/sqrt2: ((x + y) h, (y - x) h)
+    b7 = sub_mi(b7, b7) * (-h);                                    // * (-1 - i)/sqrt2: ((y - x) h, -(x + y) h)
     {   // even outputs
-        float2 d0 = cadd(b0, b2), d2 = csub(b0, b2), d1 = cadd(b1, b3), d3 = mul_mi(csub(b1, b3));
-        a[0] = cadd(d0, d1); a[4] = csub(d0, d1); a[2] = cadd(d2, d3); a[6] = csub(d2, d3);
+        const v2f d0 = b0 + b2, d2 = b0 - b2, d1 = b1 + b3, t = b1 - b3;
+        a[0] = d0 + d1; a[4] = d0 - d1; a[2] = add_mi(d2, t); a[6] = sub_mi(d2, t);
     }
-    {   // odd outputs
-        float2 d0 = cadd(b4, b6), d2 = csub(b4, b6), d1 = cadd(b5, b7), d3 = mul_mi(csub(b5, b7));
-        a[1] = cadd(d0, d1); a[5] = csub(d0, d1); a[3] = cadd(d2, d3); a[7] = csub(d2, d3);
+    {   // odd outputs (b6 enters multiplied by -i)
+        const v2f d0 = add_mi(b4, b6), d2 = sub_mi(b4, b6), d1 = b5 + b7, t = b5 - b7;
+        a[1] = d0 + d1; a[5] = d0 - d1; a[3] = add_mi(d2, t); a[7] = sub_mi(d2, t);
     }
 }
 
 // Per-lane constants of the transform, loaded once per workgroup into registers: the lane's 16 window
-// taps, its pass-2 / pass-3 twiddles and the untangle twiddles of its 9 bins.
+// taps (pre-scaled by 2^-15, the int16 -> [-1, 1) factor: exact), its pass-2 / pass-3 twiddles and the untangle
+// twiddles of its 9 bins, the latter pre-multiplied by -i (exact: a swap and a sign).
 struct StConst {
-    float2 win[8];      // window[2n], window[2n+1] for n = lane + 64 t
-    float2 tw2[7];      // w512[t * (lane & 7) * 8], t = 1..7
-    float2 tw3[7];      // w512[t * lane],           t = 1..7
-    float2 twu[9];      // w1024[lane + 64 t],       t = 0..8
+    v2f win[8];      // window[2n], window[2n+1] for n = lane + 64 t
+    v2f tw2[7];      // w512[t * (lane & 7) * 8], t = 1..7
+    v2f tw3[7];      // w512[t * lane],           t = 1..7
+    v2f twu[9];      // -i w1024[lane + 64 t],    t = 0..8
 };
 __device__ __forceinline__ void load_const(StConst &c, const float *__restrict__ window, const float2 *__restrict__ g512,
                                            const float2 *__restrict__ g1024, int lane)
 {
+    auto ld = [](const float2 *p) { const float2 v = *p; return v2f{v.x, v.y}; };
 #pragma unroll
-    for (int t = 0; t < 8; t++) c.win[t] = *reinterpret_cast<const float2 *>(window + 2 * (lane + 64 * t));
+    for (int t = 0; t < 8; t++) c.win[t] = ld(reinterpret_cast<const float2 *>(window + 2 * (lane + 64 * t))) * (1.0f / 32768.0f);
 #pragma unroll
-    for (int t = 1; t < 8; t++) { c.tw2[t - 1] = g512[t * (lane & 7) * 8]; c.tw3[t - 1] = g512[t * lane]; }
+    for (int t = 1; t < 8; t++) { c.tw2[t - 1] = ld(g512 + t * (lane & 7) * 8); c.tw3[t - 1] = ld(g512 + t * lane); }
 #pragma unroll
-    for (int t = 0; t < 9; t++) c.twu[t] = g1024[min(lane + 64 * t, MC)];
+    for (int t = 0; t < 9; t++) { const v2f w = ld(g1024 + min(lane + 64 * t, MC)); c.twu[t] = v2f{w.y, -w.x}; }
 }
 
 // One frame.  zb: this wave's LDS buffer.  Calls sink(k, magnitude) for k = lane + 64 t (t = 0..7) and k = 512 on lane 0;
 // with SQUARED the sink receives |X|^2 (the maximum pass: sqrt is monotone, one square root per clip instead of 9 per lane and frame).
 template <bool SQUARED, class Sink>
 __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, const StClip &cl, int frame, int hop, const StConst &C,
-                                           float2 *zb, int lane, Sink sink)
+                                           float2 *zb_, int lane, Sink sink)
 {
-    float2 a[8];
+    v2f *zb = reinterpret_cast<v2f *>(zb_);
+    v2f a[8];
     const int64_t s0 = (int64_t)frame * hop - NFFT / 2;            // first sample of the centred frame
     const bool interior = s0 >= 0 && s0 + NFFT <= cl.len && (((cl.pcm_off + s0) & 1) == 0);
 #pragma unroll
@@ -96,13 +125,13 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
         float x0 = 0.f, x1 = 0.f;
         if (interior) {
             const int v = *reinterpret_cast<const int *>(pcm + cl.pcm_off + i0);   // 4-byte aligned pair
-            x0 = (float)(short)(v & 0xFFFF) * (1.0f / 32768.0f);
-            x1 = (float)(v >> 16) * (1.0f / 32768.0f);
+            x0 = (float)(short)(v & 0xFFFF);
+            x1 = (float)(v >> 16);
         } else {
-            if (i0 >= 0 && i0 < cl.len) x0 = (float)pcm[cl.pcm_off + i0] * (1.0f / 32768.0f);
-            if (i0 + 1 >= 0 && i0 + 1 < cl.len) x1 = (float)pcm[cl.pcm_off + i0 + 1] * (1.0f / 32768.0f);
+            if (i0 >= 0 && i0 < cl.len) x0 = (float)pcm[cl.pcm_off + i0];
+            if (i0 + 1 >= 0 && i0 + 1 < cl.len) x1 = (float)pcm[cl.pcm_off + i0 + 1];
         }
-        a[t] = make_float2(x0 * C.win[t].x, x1 * C.win[t].y);
+        a[t] = v2f{x0, x1} * C.win[t];                             // (x / 32768) * w == x * (w / 32768): power-of-two scaling is exact
     }
     // pass 1 (Ns = 1): no twiddles
     dft8(a);
@@ -140,16 +169,18 @@ __device__ __forceinline__ void stft_frame(const int16_t *__restrict__ pcm, cons
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // untangle the packed real transform: X[k] = E[k] + w^k O[k]
+    // untangle the packed real transform: X[k] = E[k] + w^k O[k], E = (z[k] + conj z[M-k]) / 2, O = -i (z[k] - conj z[M-k]) / 2;
+    // the -i sits in the twiddle constant
 #pragma unroll
     for (int t = 0; t <= 8; t++) {
         const int k = lane + 64 * t;
         if (t == 8 && lane != 0) break;
-        const float2 zk = zb[ZPAD(k & (MC - 1))], zm = zb[ZPAD((MC - k) & (MC - 1))];
-        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-        const float2 o = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
-        const float2 x = cadd(e, cmul(C.twu[t], o));
-        const float p2 = x.x * x.x + x.y * x.y;
+        const v2f zk = zb[ZPAD(k & (MC - 1))], zm = zb[ZPAD((MC - k) & (MC - 1))];
+        const v2f e = add_conj(zk, zm) * 0.5f;
+        const v2f o = sub_conj(zk, zm) * 0.5f;
+        const v2f x = e + cmul(o, C.twu[t]);
+        const v2f xx = x * x;
+        const float p2 = xx.x + xx.y;
         sink(k, SQUARED ? p2 : sqrtf(p2));           // |x| <= 1024: no overflow; np.abs differs by <= 1 ulp
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
