@@ -233,3 +233,33 @@ def test_pitch_reuses_the_energy_pass_only_for_the_same_slices(engine, synth16k)
     engine.energy_run(sl, 123)                                 # another gate threshold does not matter for sums / extrema
     assert pitch() == alone
     assert engine.energy_fetch()["sum_sq"].tolist() == [int((c.astype(np.int64) ** 2).sum()) for c in clips]
+
+
+@pytest.mark.gpu
+def test_c4_shard_size_batch_equals_its_sub_batches():
+    """BASELINE.json C4: 10 000 clips over 8 GPUs = 1 250 ten-second clips per rank in ONE resident batch.  Every
+    per-utterance result must equal what five sub-batches of 250 give (utterances are independent: the batch size,
+    the work lists and the XCD tile order may not leak into the numbers)."""
+    import hashlib
+    n, part = 1250, 250
+    clips = synth.synth_batch(n, 10.0, 16000, first=5000)
+    p = pkg.PitchParams.praat(150.0, 600.0)
+
+    def measure(eng, batch):
+        eng.upload(batch, 16000); sl = eng.whole_clip_slices()
+        eng.energy_run(sl, 500); eng.lufs_run(sl); eng.pitch_run(sl, p); eng.stft_db_run(1024, 256); eng.frame_energy_run(800)
+        en = eng.energy_fetch(); lu = eng.lufs_fetch()[0]; pi = eng.pitch_fetch(want_f0=True)
+        picks = range(0, len(batch), 50)
+        stft = [hashlib.sha256(eng.stft_db_fetch(i).tobytes()).hexdigest() for i in picks]
+        fr = [eng.frame_energy_fetch(i)[0].tobytes() for i in picks]
+        off = pi["frame_offsets"]
+        f0 = [pi["f0"][off[i]:off[i + 1]].tobytes() for i in range(len(batch))]
+        return en.tobytes(), lu.tobytes(), pi["summary"]["median_f0"].tobytes(), pi["summary"]["n_voiced"].tobytes(), f0, stft, fr
+
+    with pkg.ProsodyEngine(0) as eng:
+        whole = measure(eng, clips)
+        parts = [measure(eng, clips[k:k + part]) for k in range(0, n, part)]
+    for j in range(4):
+        assert whole[j] == b"".join(pt[j] for pt in parts), j
+    for j in (4, 5, 6):
+        assert whole[j] == [x for pt in parts for x in pt[j]], j
