@@ -250,6 +250,19 @@ int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32
 int pce_nw_align(pce_ctx *ctx, const int32_t *a_ids, const int64_t *a_off, const int32_t *b_ids, const int64_t *b_off, int32_t batch,
                  int32_t match, int32_t mismatch, int32_t gap, int32_t *out_i, int32_t *out_j, int32_t *out_len);
 
+/* ---- break-prediction token classifier --------------------
+ * Forward pass of transformers.BertForTokenClassification, the model Code/baseline_models/pause_bert.py:127-132 trains
+ * (bert-base-multilingual-uncased, num_labels = 2, MAX_LENGTH = 128; the reference has training code only: this is the
+ * inference path a pipeline step would call).  weights: the float32 state_dict flattened in the order of
+ * prosody-control-french-tts_amd/bert_weights.py:tensor_order.  Sequences are token ids (tokenisation is host logic and
+ * needs the checkpoint's vocabulary); token_type_ids = 0, right padding is implicit in the offsets.  bf16 MFMA
+ * operands, fp32 accumulation, LayerNorm / residual stream / logits in fp32. */
+typedef struct pce_bert_dims { int32_t n_vocab, n_pos, n_type, n_state, n_head, n_layer, n_labels; } pce_bert_dims;
+int pce_bert_load(pce_ctx *ctx, const pce_bert_dims *dims, const float *weights, int64_t n_floats);
+int pce_bert_run(pce_ctx *ctx, const int32_t *input_ids, const int32_t *offsets /* [n_seq + 1] */, int32_t n_seq);
+/* logits: [len][n_labels] or NULL; labels: [len] argmax (first maximum) or NULL */
+int pce_bert_fetch(pce_ctx *ctx, int32_t seq, float *logits, int32_t *labels);
+
 /* ---- asynchronous statistics fetch ---------------------------------------
  * The per-slice numbers of the last pce_energy_run / pce_lufs_run / pce_pitch_run are what the reference's
  * driver consumes per utterance (Code/audioPipeline.py:380-400) and what the sharded driver all-gathers
@@ -268,7 +281,7 @@ enum pce_kernel_id {
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
     PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN, PCE_K_NW, PCE_K_STFT_NORM,
-    PCE_K_FRAME_ENERGY, PCE_K_COUNT
+    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

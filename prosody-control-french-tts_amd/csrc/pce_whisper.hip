@@ -528,9 +528,9 @@ template <> __device__ __forceinline__ void ln_store4<bf16>(bf16 *p, float a, fl
 }
 
 template <class OUT>
-__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
-                                                  int64_t rows, int d, OUT *__restrict__ out)
-{
+__global__ __launch_bounds__(256) void k_layernorm(const float *x, const float *__restrict__ w, const float *__restrict__ b,
+                                                  int64_t rows, int d, OUT *__restrict__ out, float eps = 1e-5f, float *out2 = nullptr)
+{   // out2 (optional, may alias x): the same values in fp32 -- the post-LN residual stream of the BERT layers
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -555,14 +555,16 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
         }
     }
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-    const float inv = rsqrtf(q / (float)d + 1e-5f);
+    const float inv = rsqrtf(q / (float)d + eps);
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
             const float4 ww = reinterpret_cast<const float4 *>(w)[idx], bb = reinterpret_cast<const float4 *>(b)[idx];
-            ln_store4<OUT>(out + row * d + 4 * idx, (v[i].x - mean) * inv * ww.x + bb.x, (v[i].y - mean) * inv * ww.y + bb.y,
-                           (v[i].z - mean) * inv * ww.z + bb.z, (v[i].w - mean) * inv * ww.w + bb.w);
+            const float y0 = (v[i].x - mean) * inv * ww.x + bb.x, y1 = (v[i].y - mean) * inv * ww.y + bb.y,
+                        y2 = (v[i].z - mean) * inv * ww.z + bb.z, y3 = (v[i].w - mean) * inv * ww.w + bb.w;
+            ln_store4<OUT>(out + row * d + 4 * idx, y0, y1, y2, y3);
+            if (out2) ln_store4<float>(out2 + row * d + 4 * idx, y0, y1, y2, y3);
         }
     }
 }
@@ -779,6 +781,17 @@ __global__ void k_embed_tokens(const int *__restrict__ tokens /* [clips][T_pad] 
     out[i] = tok_emb[(int64_t)tokens[m] * d + col] + pos_emb[(int64_t)t * d + col];
 }
 
+// BERT embeddings: word[id] + token_type[0] + position[t] (the LayerNorm follows as its own launch)
+__global__ void k_bert_embed(const int *__restrict__ tokens /* [seqs][T_pad] */, const float *__restrict__ word, const float *__restrict__ pos,
+                             const float *__restrict__ type0, int T_pad, int n_pos, int d, int64_t rows, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * d) return;
+    const int64_t m = i / d; const int col = (int)(i - m * d);
+    int t = (int)(m % T_pad); if (t >= n_pos) t = n_pos - 1;        // pad rows: any finite value
+    out[i] = (word[(int64_t)tokens[m] * d + col] + type0[col]) + pos[(int64_t)t * d + col];
+}
+
 // softmax over the audio frames of the (scaled) cross-attention logits of one alignment head:
 // w[clip][sel][t][s] = softmax_s(q_t . k_s * 0.125 * qk_scale), s < F_c.  16 tokens per workgroup, 4 waves x 16
 // keys per 64-key tile on v_mfma_f32_16x16x32_bf16, two passes (row max / sum, then normalised write).
@@ -988,6 +1001,18 @@ struct WhisperState {
     MelTables mt{};
     int mel_nmels = 0;
     int32_t n_clips_mel = -1, n_clips_enc = -1;
+    // break-prediction token classifier (BertForTokenClassification)
+    struct Bert {
+        pce_bert_dims dims{};
+        bool loaded = false;
+        DevBuf w_bf16, w_f32, word, pos, type0;
+        DevBuf tab, tokens, resid, ln, qk, vt, attn, hidden, logits;
+        struct Layer { size_t qkv_w, qkv_b, out_w, out_b, ln1_w, ln1_b, m1_w, m1_b, m2_w, m2_b, ln2_w, ln2_b; };
+        std::vector<Layer> layers;
+        size_t lne_w = 0, lne_b = 0, cls_w = 0, cls_b = 0;
+        int n_seq = -1, T_pad = 0;
+        std::vector<int> lens;
+    } bert;
     // offsets (elements) into w_bf16 / w_f32
     struct Layer { size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, ln2_w, ln2_b, m1_w, m1_b, m2_w, m2_b; };
     size_t c1_w = 0, c1_b = 0, c2_w = 0, c2_b = 0, lnp_w = 0, lnp_b = 0;
@@ -1102,7 +1127,9 @@ void pce_whisper_free(pce_ctx *c)
     DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
                       &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
-                      &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out};
+                      &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
+                      &w->bert.w_bf16, &w->bert.w_f32, &w->bert.word, &w->bert.pos, &w->bert.type0, &w->bert.tab, &w->bert.tokens, &w->bert.resid,
+                      &w->bert.ln, &w->bert.qk, &w->bert.vt, &w->bert.attn, &w->bert.hidden, &w->bert.logits};
     for (auto b : bufs) b->release();
     delete w;
     c->whisper = nullptr;
@@ -1564,3 +1591,176 @@ int pce_whisper_align_shape(pce_ctx *c, int32_t clip, int32_t *n_rows, int32_t *
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// Break-prediction token classifier: BertForTokenClassification forward (post-LN encoder layers on the same GEMM /
+// attention / LayerNorm kernels as the Whisper encoder; Code/baseline_models/pause_bert.py:127-132).
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int pce_bert_load(pce_ctx *c, const pce_bert_dims *dims, const float *weights, int64_t n_floats)
+{
+    if (!c || !dims || !weights) return PCE_E_INVALID;
+    const int d = dims->n_state, L = dims->n_layer, V = dims->n_vocab, P = dims->n_pos, TY = dims->n_type, NL = dims->n_labels;
+    if (d <= 0 || d % 128 || dims->n_head * 64 != d || L <= 0 || V <= 0 || P <= 0 || P > 512 || TY <= 0 || NL <= 0 || NL > 128)
+        return pce_fail(c, PCE_E_LIMIT, "unsupported BERT dims (need n_state %% 128 == 0, head size 64, n_pos <= 512, n_labels <= 128)");
+    const int64_t dd = (int64_t)d * d;
+    const int64_t per_layer = 4 * (dd + d) + 2LL * d + (4 * dd + 4LL * d) + (4 * dd + d) + 2LL * d;
+    const int64_t expect = ((int64_t)V + P + TY) * d + 2LL * d + L * per_layer + (int64_t)NL * (d + 1);
+    if (n_floats != expect) return pce_fail(c, PCE_E_INVALID, "BERT weight blob has %lld floats, expected %lld", (long long)n_floats, (long long)expect);
+    PCE_HIP(c, hipSetDevice(c->device));
+    WhisperState::Bert &b = ws_of(c)->bert;
+    b.dims = *dims; b.loaded = false; b.n_seq = -1; b.layers.assign((size_t)L, {});
+    std::vector<float> mats, vecs;
+    auto add_vec = [&](const float *p, size_t n) { size_t o = vecs.size(); vecs.insert(vecs.end(), p, p + n); return o; };
+    auto add_mat = [&](const float *p, size_t n) { size_t o = mats.size(); mats.insert(mats.end(), p, p + n); return o; };
+    const float *p = weights;
+    const float *word = p; p += (size_t)V * d;
+    const float *pos = p; p += (size_t)P * d;
+    const float *type = p; p += (size_t)TY * d;
+    b.lne_w = add_vec(p, (size_t)d); p += d; b.lne_b = add_vec(p, (size_t)d); p += d;
+    for (int l = 0; l < L; l++) {
+        WhisperState::Bert::Layer &ly = b.layers[(size_t)l];
+        const float *qw = p, *qb = qw + dd, *kw = qb + d, *kb = kw + dd, *vw = kb + d, *vb = vw + dd;
+        ly.qkv_w = add_mat(qw, (size_t)dd); add_mat(kw, (size_t)dd); add_mat(vw, (size_t)dd);          // fused [3d][d]
+        ly.qkv_b = add_vec(qb, (size_t)d); add_vec(kb, (size_t)d); add_vec(vb, (size_t)d);
+        p = vb + d;
+        ly.out_w = add_mat(p, (size_t)dd); p += dd; ly.out_b = add_vec(p, (size_t)d); p += d;
+        ly.ln1_w = add_vec(p, (size_t)d); p += d; ly.ln1_b = add_vec(p, (size_t)d); p += d;
+        ly.m1_w = add_mat(p, (size_t)(4 * dd)); p += 4 * dd; ly.m1_b = add_vec(p, (size_t)4 * d); p += 4 * d;
+        ly.m2_w = add_mat(p, (size_t)(4 * dd)); p += 4 * dd; ly.m2_b = add_vec(p, (size_t)d); p += d;
+        ly.ln2_w = add_vec(p, (size_t)d); p += d; ly.ln2_b = add_vec(p, (size_t)d); p += d;
+    }
+    {   // classifier [n_labels][d] padded with zero rows to one 128-column GEMM tile
+        std::vector<float> cw((size_t)128 * d, 0.f), cb(128, 0.f);
+        memcpy(cw.data(), p, sizeof(float) * (size_t)NL * d); p += (size_t)NL * d;
+        memcpy(cb.data(), p, sizeof(float) * (size_t)NL); p += NL;
+        b.cls_w = add_mat(cw.data(), cw.size()); b.cls_b = add_vec(cb.data(), cb.size());
+    }
+    DevBuf tmp;
+    PCE_HIP(c, tmp.reserve(sizeof(float) * mats.size()));
+    PCE_HIP(c, b.w_bf16.reserve(sizeof(bf16) * mats.size() + 256));
+    PCE_HIP(c, b.w_f32.reserve(sizeof(float) * vecs.size()));
+    PCE_HIP(c, b.word.reserve(sizeof(float) * (size_t)V * d));
+    PCE_HIP(c, b.pos.reserve(sizeof(float) * (size_t)P * d));
+    PCE_HIP(c, b.type0.reserve(sizeof(float) * (size_t)d));
+    PCE_HIP(c, hipMemcpyAsync(tmp.p, mats.data(), sizeof(float) * mats.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(b.w_f32.p, vecs.data(), sizeof(float) * vecs.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(b.word.p, word, sizeof(float) * (size_t)V * d, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(b.pos.p, pos, sizeof(float) * (size_t)P * d, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(b.type0.p, type, sizeof(float) * (size_t)d, hipMemcpyHostToDevice, c->stream));      // token_type_ids = 0
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up((int64_t)mats.size(), 256)), dim3(256), 0, c->stream, tmp.as<float>(),
+                       b.w_bf16.as<bf16>(), (int64_t)mats.size());
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    b.loaded = true;
+    return PCE_OK;
+}
+
+int pce_bert_run(pce_ctx *c, const int32_t *input_ids, const int32_t *offsets, int32_t n_seq)
+{
+    if (!c || !input_ids || !offsets || n_seq < 0) return PCE_E_INVALID;
+    WhisperState::Bert &b = ws_of(c)->bert;
+    if (!b.loaded) return pce_fail(c, PCE_E_STATE, "pce_bert_run before pce_bert_load");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int d = b.dims.n_state, H = b.dims.n_head, L = b.dims.n_layer, V = b.dims.n_vocab, n = n_seq, SPD = 512;
+    b.n_seq = -1;
+    b.lens.assign((size_t)n, 0);
+    int T_max = 0;
+    for (int i = 0; i < n; i++) {
+        const int T = offsets[i + 1] - offsets[i];
+        if (T < 1 || T > b.dims.n_pos) return pce_fail(c, PCE_E_INVALID, "sequence %d: %d tokens (need 1..%d)", i, T, b.dims.n_pos);
+        b.lens[(size_t)i] = T; T_max = std::max(T_max, T);
+    }
+    if (n == 0) { b.n_seq = 0; return PCE_OK; }
+    const int T_pad = (int)div_up(T_max, 64) * 64;
+    const int64_t M = (int64_t)n * T_pad;
+    std::vector<int> tab((size_t)2 * n), tok((size_t)M, 0);
+    for (int i = 0; i < n; i++) {
+        tab[(size_t)i] = i * T_pad; tab[(size_t)n + i] = b.lens[(size_t)i];
+        for (int t = 0; t < b.lens[(size_t)i]; t++) {
+            const int v = input_ids[offsets[i] + t];
+            if (v < 0 || v >= V) return pce_fail(c, PCE_E_INVALID, "token id %d out of the vocabulary", v);
+            tok[(size_t)i * T_pad + t] = v;
+        }
+    }
+    PCE_HIP(c, b.tab.reserve(sizeof(int) * tab.size()));
+    PCE_HIP(c, b.tokens.reserve(sizeof(int) * tok.size()));
+    PCE_HIP(c, b.resid.reserve(sizeof(float) * (size_t)M * d));
+    PCE_HIP(c, b.ln.reserve(sizeof(bf16) * (size_t)M * d + 4096));
+    PCE_HIP(c, b.qk.reserve(sizeof(bf16) * (size_t)M * 2 * d + 4096));
+    PCE_HIP(c, b.attn.reserve(sizeof(bf16) * (size_t)M * d + 4096));
+    PCE_HIP(c, b.hidden.reserve(sizeof(bf16) * (size_t)M * 4 * d + 4096));
+    PCE_HIP(c, b.logits.reserve(sizeof(float) * (size_t)M * 128));
+    const size_t vt_elems = (size_t)n * (size_t)d * SPD + 64;
+    PCE_HIP(c, b.vt.reserve(sizeof(bf16) * vt_elems));
+    PCE_HIP(c, hipMemcpyAsync(b.tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(b.tokens.p, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    // the attention kernel writes the rows of real tokens only and V^T columns beyond T_pad are never written: no stale bits
+    PCE_HIP(c, hipMemsetAsync(b.attn.p, 0, sizeof(bf16) * (size_t)M * d + 4096, c->stream));
+    PCE_HIP(c, hipMemsetAsync(b.vt.p, 0, sizeof(bf16) * vt_elems, c->stream));
+    PCE_HIP(c, hipMemsetAsync(b.logits.p, 0, sizeof(float) * (size_t)M * 128, c->stream));
+    const int *T0 = b.tab.as<int>(), *TL = T0 + n;
+    const bf16 *Wb = b.w_bf16.as<bf16>();
+    const float *Wf = b.w_f32.as<float>();
+    const float eps = 1e-12f;                                    // BertConfig.layer_norm_eps
+    KernelTimer timer(c, PCE_K_BERT);
+    hipLaunchKernelGGL(k_bert_embed, dim3((unsigned)div_up(M * d, 256)), dim3(256), 0, c->stream, b.tokens.as<int>(), b.word.as<float>(),
+                       b.pos.as<float>(), b.type0.as<float>(), T_pad, b.dims.n_pos, d, M, b.resid.as<float>());
+    auto ln = [&](size_t w_off, size_t b_off) {                  // resid <- LN(resid) (fp32, in place) and its bf16 copy
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, b.resid.as<float>(), Wf + w_off, Wf + b_off,
+                           M, d, b.ln.as<bf16>(), eps, b.resid.as<float>());
+    };
+    ln(b.lne_w, b.lne_b);
+    for (int l = 0; l < L; l++) {
+        const WhisperState::Bert::Layer &ly = b.layers[(size_t)l];
+        launch_gemm<EPI_QKV>(c, b.ln.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, b.qk.as<bf16>(), 2 * d, 0, 1,
+                             reinterpret_cast<const float *>(b.vt.as<bf16>()), T_pad, 2 * d, SPD);
+        {
+            AttnArgs a{};
+            a.q = b.qk.as<bf16>(); a.q_ld = 2 * d; a.k = b.qk.as<bf16>() + d; a.k_ld = 2 * d;
+            a.vt = b.vt.as<bf16>(); a.vt_clip = (int64_t)d * SPD; a.vt_sp = SPD;
+            a.q_row0 = a.k_row0 = T0; a.q_len = a.k_len = TL;    // keys beyond the sequence length are masked (right padding)
+            a.out = b.attn.as<bf16>(); a.out_ld = d; a.causal = 0;
+            hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+        }
+        launch_gemm<EPI_RESID_F32>(c, b.attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, b.resid.as<float>(), d, 0, 1);
+        ln(ly.ln1_w, ly.ln1_b);
+        launch_gemm<EPI_GELU_BF16>(c, b.ln.as<bf16>(), d, 0, Wb + ly.m1_w, (int)M, 4 * d, d, Wf + ly.m1_b, b.hidden.as<bf16>(), 4 * d, 0, 1);
+        launch_gemm<EPI_RESID_F32>(c, b.hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, (int)M, d, 4 * d, Wf + ly.m2_b, b.resid.as<float>(), d, 0, 1);
+        ln(ly.ln2_w, ly.ln2_b);
+    }
+    // classifier: logits[M][128] = 0 + hidden . W^T + b (the first n_labels columns are real)
+    launch_gemm<EPI_RESID_F32>(c, b.ln.as<bf16>(), d, 0, Wb + b.cls_w, (int)M, 128, d, Wf + b.cls_b, b.logits.as<float>(), 128, 0, 1);
+    PCE_HIP(c, hipGetLastError());
+    b.n_seq = n; b.T_pad = T_pad;
+    return PCE_OK;
+}
+
+int pce_bert_fetch(pce_ctx *c, int32_t seq, float *logits, int32_t *labels)
+{
+    if (!c) return PCE_E_INVALID;
+    WhisperState::Bert &b = ws_of(c)->bert;
+    if (b.n_seq < 0) return pce_fail(c, PCE_E_STATE, "pce_bert_fetch before pce_bert_run");
+    if (seq < 0 || seq >= b.n_seq) return pce_fail(c, PCE_E_INVALID, "sequence out of range");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int T = b.lens[(size_t)seq], NL = b.dims.n_labels;
+    std::vector<float> rows((size_t)T * 128);
+    PCE_HIP(c, hipMemcpyAsync(rows.data(), b.logits.as<float>() + (size_t)seq * b.T_pad * 128, sizeof(float) * rows.size(), hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    for (int t = 0; t < T; t++) {
+        int best = 0;
+        for (int k = 0; k < NL; k++) {
+            const float v = rows[(size_t)t * 128 + k];
+            if (logits) logits[(size_t)t * NL + k] = v;
+            if (v > rows[(size_t)t * 128 + best]) best = k;          // first maximum, as argmax
+        }
+        if (labels) labels[t] = best;
+    }
+    return PCE_OK;
+}
+
+} // extern "C"
+

@@ -70,6 +70,11 @@ class WhisperTextDims(C.Structure):
     _fields_ = [("n_vocab", C.c_int32), ("n_text_ctx", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32)]
 
 
+class BertDims(C.Structure):
+    _fields_ = [("n_vocab", C.c_int32), ("n_pos", C.c_int32), ("n_type", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32),
+                ("n_layer", C.c_int32), ("n_labels", C.c_int32)]
+
+
 SLICE_DTYPE = np.dtype([("clip", "<i4"), ("flags", "<i4"), ("begin", "<i8"), ("end", "<i8"), ("x1", "<f8")])
 ENERGY_DTYPE = np.dtype([("n", "<i8"), ("sum_sq", "<i8"), ("sum_sq_wrap16", "<i8"), ("n_loud", "<i8"),
                          ("peak_abs", "<i4"), ("reserved", "<i4")])
@@ -81,7 +86,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -93,7 +98,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_resample_run", "pce_download_pcm_s16",
            "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch",
            "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
-           "pce_stats_enqueue", "pce_stats_wait",
+           "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
 
@@ -136,6 +141,9 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_align_run.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_float]
     lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
+    lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
+    lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
+    lib.pce_bert_fetch.argtypes = [vp, i32, vp, vp]
     lib.pce_logmel_run.argtypes = [vp, i32]
     lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
@@ -430,6 +438,30 @@ class ProsodyEngine:
         ss = np.zeros(nf.value, dtype=np.int64); cnt = np.zeros(nf.value, dtype=np.int32)
         self._check(self._lib.pce_frame_energy_fetch(self._ctx, int(clip), ss.ctypes.data, cnt.ctypes.data))
         return ss, cnt
+
+    # ---------------------------------------------------------------- break-prediction token classifier
+    def bert_load(self, dims: dict, weights: np.ndarray):
+        """``weights``: float32 blob in ``bert_weights.tensor_order`` (``bert_weights.pack(model.state_dict(), dims)``)."""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        self._bdims = BertDims(*(dims[k] for k in ("n_vocab", "n_pos", "n_type", "n_state", "n_head", "n_layer", "n_labels")))
+        self._check(self._lib.pce_bert_load(self._ctx, C.byref(self._bdims), w.ctypes.data, w.size))
+
+    def bert_run(self, token_lists):
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32) for t in token_lists] + [np.zeros(0, np.int32)]), dtype=np.int32)
+        off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
+        self._bert_lens = [len(t) for t in token_lists]
+        self._check(self._lib.pce_bert_run(self._ctx, toks.ctypes.data, off.ctypes.data, len(token_lists)))
+
+    def bert_fetch(self, seq: int):
+        """-> (logits float32 [len][n_labels], labels int32 [len])."""
+        n = self._bert_lens[seq]
+        logits = np.zeros((n, self._bdims.n_labels), dtype=np.float32); labels = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.pce_bert_fetch(self._ctx, int(seq), logits.ctypes.data, labels.ctypes.data))
+        return logits, labels
+
+    def bert_token_classify(self, token_lists):
+        self.bert_run(token_lists)
+        return [self.bert_fetch(i) for i in range(len(token_lists))]
 
     def nw_align(self, pairs, match=1, mismatch=-1, gap=-1):
         """Batched Needleman-Wunsch over integer token ids: ``pairs`` = [(ids_a, ids_b), ...] ->
