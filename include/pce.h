@@ -179,6 +179,24 @@ int pce_stft_db_fetch(pce_ctx *ctx, int32_t clip, float *out);
 /* device pointer + byte size of the resident result (all clips, concatenated) */
 int pce_stft_db_device(pce_ctx *ctx, const void **d_ptr, int64_t *bytes);
 
+/* ---- R10: probabilistic YIN -------------------------------------------------
+ * Replaces librosa.pyin(audio, sr=sr, fmin=60, fmax=2000, hop_length=256) of the reference's viewers
+ * (Code/visualisation/app.py:74-78, acoustic_analysis.py:76-94, visualisation_abtest/app.py:108-111): frame_length 2048,
+ * win_length 1024, centred zero-padded frames, 100 thresholds with the beta(2, 18) prior, Boltzmann(2) trough prior,
+ * 0.1-semitone pitch bins, triangular local transitions, switch probability 0.01, dense Viterbi (first maximum).
+ * librosa is third party and absent: restated from its published implementation, parity unpinned.  The plan (periods,
+ * bin counts, log constants) and the constant tables are host logic (visualisation/acoustic_analysis.py builds them
+ * with numpy); the difference function is exact integer arithmetic on the int16 samples.  One decoded state per frame
+ * (state < n_pitch_bins: voiced, f0 = fmin 2^(state / bins_per_octave)) and the voiced probability. */
+typedef struct pce_pyin_plan {
+    int32_t frame_length, hop_length, min_period, max_period, n_pitch_bins, trans_width, n_thresholds, reserved;
+    double sr, fmin, bins_per_octave, no_trough_prob, log_tiny, log_p_init, tiny;
+} pce_pyin_plan;
+int pce_pyin_run(pce_ctx *ctx, const pce_pyin_plan *plan, const double *tables, int64_t n_tables);
+int pce_pyin_shape(pce_ctx *ctx, int32_t clip, int64_t *n_frames);
+/* states [n_frames] / voiced_prob [n_frames] / status (bit 0: a frame had more troughs than the engine keeps) may be NULL */
+int pce_pyin_fetch(pce_ctx *ctx, int32_t clip, int32_t *states, double *voiced_prob, int32_t *status);
+
 /* ---- R8: log-mel spectrogram + Whisper audio encoder --------------------
  * Replaces the device work of whisper_timestamped.transcribe before decoding
  * (Code/Aligners/use_whisper_timestamped.py:139,150-163; openai-whisper==20240930):
@@ -281,7 +299,7 @@ enum pce_kernel_id {
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
     PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN, PCE_K_NW, PCE_K_STFT_NORM,
-    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_COUNT
+    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

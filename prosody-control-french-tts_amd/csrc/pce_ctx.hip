@@ -149,7 +149,8 @@ void pce_destroy(pce_ctx *c)
                       &c->pi_meta, &c->pi_window, &c->pi_windowR, &c->pi_work, &c->pi_cand, &c->pi_gpeak,
                       &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc, &c->pi_rr, &c->pi_items, &c->pi_tw, &c->pi_dl, &c->pi_runs, &c->pi_fslice, &c->pi_blob,
                       &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work,
-                      &c->fr_doff, &c->fr_sum, &c->fr_cnt};
+                      &c->fr_doff, &c->fr_sum, &c->fr_cnt,
+                      &c->py_doff, &c->py_tab, &c->py_hdr, &c->py_bin, &c->py_lp, &c->py_ptr, &c->py_states};
     for (auto b : bufs) b->release();
     for (auto &st : c->stat) {
         if (st.host) (void)hipHostFree(st.host);
@@ -268,7 +269,7 @@ static int set_offsets(pce_ctx *c, const int64_t *offsets, int32_t n_clips, int3
     PCE_HIP(c, c->d_clip_off.reserve(sizeof(int64_t) * (size_t)(n_clips + 1)));
     PCE_HIP(c, hipMemcpyAsync(c->d_clip_off.p, offsets, sizeof(int64_t) * (size_t)(n_clips + 1), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
-    c->en_n = c->lu_n = c->pi_n = -1; c->st_nfft = 0; c->st_ran = false; c->fr_ran = false;
+    c->en_n = c->lu_n = c->pi_n = -1; c->st_nfft = 0; c->st_ran = false; c->fr_ran = false; c->py_ran = false;
     c->en_cache.drop(); c->lu_cache.drop(); c->pi_cache.drop();
     return PCE_OK;
 }
@@ -325,7 +326,7 @@ const char *pce_kernel_name(int id)
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
-        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward"};
+        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -104,6 +104,11 @@ struct pce_ctx {
     std::vector<int64_t> fr_off;        // frames before clip i (n_clips+1)
     bool fr_ran = false;
 
+    // probabilistic YIN
+    DevBuf py_doff, py_tab, py_hdr, py_bin, py_lp, py_ptr, py_states;
+    std::vector<int64_t> py_off;
+    bool py_ran = false;
+
     // whisper (opaque: defined in pce_whisper.hip)
     void *whisper = nullptr;
 

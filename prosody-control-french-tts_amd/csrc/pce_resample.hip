@@ -79,7 +79,7 @@ int pce_resample_run(pce_ctx *c, int32_t up, int32_t down, const double *taps, i
     c->d_clip_off = d_newoff; d_newoff.p = nullptr; d_newoff.cap = 0;
     c->clip_off = new_off;
     c->rate = (int32_t)(((int64_t)c->rate * up) / down);
-    c->en_n = c->lu_n = c->pi_n = -1; c->st_nfft = 0; c->st_ran = false; c->fr_ran = false;
+    c->en_n = c->lu_n = c->pi_n = -1; c->st_nfft = 0; c->st_ran = false; c->fr_ran = false; c->py_ran = false;
     c->en_cache.drop(); c->lu_cache.drop(); c->pi_cache.drop();
     d_taps.release();
     return PCE_OK;

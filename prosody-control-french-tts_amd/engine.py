@@ -86,13 +86,13 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
            "pce_upload_pcm_s16", "pce_bind_pcm_s16_device", "pce_num_clips",
            "pce_energy_run", "pce_energy_fetch", "pce_lufs_run", "pce_lufs_fetch",
-           "pce_frame_energy_run", "pce_frame_energy_shape", "pce_frame_energy_fetch",
+           "pce_frame_energy_run", "pce_frame_energy_shape", "pce_frame_energy_fetch", "pce_pyin_run", "pce_pyin_shape", "pce_pyin_fetch",
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
@@ -121,6 +121,9 @@ def load_library() -> C.CDLL:
     lib.pce_energy_fetch.argtypes = [vp, vp]
     lib.pce_lufs_run.argtypes = [vp, vp, i32]
     lib.pce_frame_energy_run.argtypes = [vp, i32, i32, i32]
+    lib.pce_pyin_run.argtypes = [vp, vp, vp, i64]
+    lib.pce_pyin_shape.argtypes = [vp, i32, C.POINTER(i64)]
+    lib.pce_pyin_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32)]
     lib.pce_frame_energy_shape.argtypes = [vp, i32, C.POINTER(i64)]
     lib.pce_frame_energy_fetch.argtypes = [vp, i32, vp, vp]
     lib.pce_lufs_fetch.argtypes = [vp, vp, vp]
@@ -438,6 +441,20 @@ class ProsodyEngine:
         ss = np.zeros(nf.value, dtype=np.int64); cnt = np.zeros(nf.value, dtype=np.int32)
         self._check(self._lib.pce_frame_energy_fetch(self._ctx, int(clip), ss.ctypes.data, cnt.ctypes.data))
         return ss, cnt
+
+    # ---------------------------------------------------------------- probabilistic YIN (viewers)
+    def pyin_run(self, plan, tables):
+        """``plan`` / ``tables`` from ``visualisation.acoustic_analysis.pyin_plan``."""
+        t = np.ascontiguousarray(tables, dtype=np.float64)
+        self._check(self._lib.pce_pyin_run(self._ctx, C.byref(plan), t.ctypes.data, t.size))
+
+    def pyin_fetch(self, clip: int):
+        """-> (states int32 [n_frames], voiced_prob float64 [n_frames], status)."""
+        nf = C.c_int64()
+        self._check(self._lib.pce_pyin_shape(self._ctx, int(clip), C.byref(nf)))
+        st = np.zeros(nf.value, dtype=np.int32); vp = np.zeros(nf.value, dtype=np.float64); status = C.c_int32()
+        self._check(self._lib.pce_pyin_fetch(self._ctx, int(clip), st.ctypes.data, vp.ctypes.data, C.byref(status)))
+        return st, vp, status.value
 
     # ---------------------------------------------------------------- break-prediction token classifier
     def bert_load(self, dims: dict, weights: np.ndarray):
