@@ -37,7 +37,10 @@ def test_mel_filterbank_known_values():
     assert w.shape == (80, 201) and abs(float(w[0, 1]) - 0.02486259) < 1e-7 and (w > 0).sum() == 391
 
 
-@pytest.mark.parametrize("dims", [dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2), WW.DIMS["tiny"]])
+@pytest.mark.parametrize("dims", [dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2), WW.DIMS["tiny"],
+                                  # the widths of "small" (BASELINE C3) and "medium" (the reference's default, config.yaml:15),
+                                  # two layers each: the 128 x 256 GEMM with the fused QKV / V-transpose epilogue only runs at these
+                                  dict(WW.DIMS["small"], n_layer=2), dict(WW.DIMS["medium"], n_layer=2)])
 def test_encoder_matches_torch(engine, clips, dims):
     W = WW.synthetic_weights(dims)
     engine.upload(clips[:2], 16000)
@@ -76,12 +79,13 @@ def test_dtw_indices_bit_exact(engine):
         assert gi[0] == 0 and gj[0] == 0 and gi[-1] == 89 and gj[-1] == 1499 and np.all(np.diff(gi) >= 0) and np.all(np.diff(gj) >= 0)
 
 
-def test_forced_alignment_matches_torch(engine, clips):
+@pytest.mark.parametrize("width,heads", [(128, 2), (768, 12)])
+def test_forced_alignment_matches_torch(engine, clips, width, heads):
     """Teacher-forced decoder + cross-attention alignment (openai-whisper find_alignment up to the DTW path).
     The cost matrix agrees with the torch fp32 restatement within bf16 tolerance; the GPU DTW path is EXACTLY the
     CPU recurrence's path on the GPU's own cost matrix (alignment indices bit-exact given identical costs)."""
-    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
-    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=4)
+    edims = dict(n_mels=80, n_ctx=1500, n_state=width, n_head=heads, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=width, n_head=heads, n_layer=4)     # 768: the width of "small" (wide cross K/V GEMM)
     We, Wd = WW.synthetic_weights(edims), WW.synthetic_decoder_weights(tdims)
     use = clips[:2]
     engine.upload(use, 16000)
