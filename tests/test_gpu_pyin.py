@@ -68,3 +68,14 @@ def test_pyin_errors(engine):
     engine.upload([np.zeros(10, np.int16)], 16000)
     with pytest.raises(PceError):
         engine.pyin_fetch(0)
+
+
+@pytest.mark.parametrize("rate", [8000, 22050])
+def test_pyin_other_rates_take_the_generic_lag_grouping(engine, rate):
+    rng = np.random.default_rng(rate)
+    t = np.arange(int(0.6 * rate)) / rate
+    tone = np.round(7000 * np.sin(2 * np.pi * (140.0 + 30 * t) * t) + 150 * rng.standard_normal(len(t))).astype(np.int16)
+    clips = [tone, (rng.standard_normal(3000) * 900).astype(np.int16)]
+    engine.upload(clips, rate)
+    for c, got in zip(clips, AA.pyin_batch(engine)):
+        _compare(got, PO.pyin(c.astype(np.float32) / np.float32(32768.0), rate, exact=True), 0.995, 1e-9)
