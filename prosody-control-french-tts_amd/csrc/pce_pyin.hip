@@ -341,12 +341,20 @@ __global__ __launch_bounds__(VT_THREADS) void k_pyin_viterbi(const int64_t *__re
                         if (c > b0) { b0 = c; i0 = ci; }
                         if (c > b1) { b1 = c; i1 = ci; }
                     }
-                    for (int k = klo; k <= khi; k++) {
-                        const double pv = Vv[k];
-                        const double same = lt(k, j - k, false), sw = lt(k, j - k, true);
+                    // ascending k (= descending e = j - k), fixed trip count with a validity test.  The two table rows of a
+                    // state are 1.1 KB and are re-read every frame: 1.45 MB per frame and workgroup through L2 -> L1, which
+                    // at the ~56 GB/s a CU draws from L2 is the 29 us per frame this kernel takes (18 ms per 626-frame clip,
+                    // one CU per clip); the table (690 KB) fits neither LDS nor registers
+#pragma unroll 8
+                    for (int e = half; e >= -half; e--) {
+                        const int k = j - e;
+                        const bool ok = k >= 0 && k < nb;
+                        const int kk = ok ? k : j;
+                        const double pv = Vv[kk];
+                        const double same = lt(kk, ok ? e : 0, false), sw = lt(kk, ok ? e : 0, true);
                         const double c0v = pv + (v == 0 ? same : sw), c1v = pv + (v == 0 ? sw : same);
-                        if (c0v > b0) { b0 = c0v; i0 = v * nb + k; }
-                        if (c1v > b1) { b1 = c1v; i1 = v * nb + k; }
+                        if (ok && c0v > b0) { b0 = c0v; i0 = v * nb + k; }
+                        if (ok && c1v > b1) { b1 = c1v; i1 = v * nb + k; }
                     }
                     if (khi < nb - 1) {
                         const double c = smv[v * nb + khi + 1] + P.c0; const int ci = v * nb + smi[v * nb + khi + 1];
