@@ -341,10 +341,11 @@ __global__ __launch_bounds__(VT_THREADS) void k_pyin_viterbi(const int64_t *__re
                         if (c > b0) { b0 = c; i0 = ci; }
                         if (c > b1) { b1 = c; i1 = ci; }
                     }
-                    // ascending k (= descending e = j - k), fixed trip count with a validity test.  The two table rows of a
-                    // state are 1.1 KB and are re-read every frame: 1.45 MB per frame and workgroup through L2 -> L1, which
-                    // at the ~56 GB/s a CU draws from L2 is the 29 us per frame this kernel takes (18 ms per 626-frame clip,
-                    // one CU per clip); the table (690 KB) fits neither LDS nor registers
+                    // ascending k (= descending e = j - k), fixed trip count with a validity test.  29 us per frame (18 ms per
+                    // 626-frame clip, one CU per clip): 284 table loads per state and frame (the 690 KB table fits neither
+                    // LDS nor registers).  Sending the interior rows as a base row + int8 bit-pattern differences (an eighth
+                    // of the bytes, same number of load instructions) measured 2.6x SLOWER: the loop is bound by load
+                    // instructions, not bytes.
 #pragma unroll 8
                     for (int e = half; e >= -half; e--) {
                         const int k = j - e;
