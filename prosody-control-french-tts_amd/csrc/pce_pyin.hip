@@ -29,7 +29,7 @@ struct PyPlan {
     int hop, min_period, max_period, n_tau, n_bins, half, n_thr, n_groups;
     double sr, fmin, bins_per_octave, no_trough_prob, c0 /* log(tiny) */, log_pinit, tiny;
     // offsets (doubles) into the table blob
-    int o_thr, o_beta, o_bprefix, o_bfac, o_bexp, o_lt_same, o_lt_sw;      // log transition tables: [e + half][k], k = predecessor bin
+    int o_thr, o_beta, o_bprefix, o_bfac, o_bexp, o_lt_same, o_lt_sw;      // log transition table: [e + half][k][same | switch], k = predecessor bin
 };
 struct PyObs { int n; int status; double voiced_prob; double log_unvoiced; };   // per frame header
 // per frame: header + PY_MAXTR (bin, log-prob) pairs
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(VT_THREADS) void k_pyin_viterbi(const int64_t *__re
     if (T <= 0) return;
     // log T[k -> j] for predecessor k (bin) and e = j - k in [-half, half].  librosa normalises every row by its own
     // sum over all n_bins entries, whose rounding differs from row to row by an ulp: the table keeps every row.
-    auto lt = [&](int k, int e, bool sw) -> double { return tab[(sw ? P.o_lt_sw : P.o_lt_same) + (e + half) * nb + k]; };
+    // (same-voicing, switching) pairs interleaved [e + half][k][2]: one 16-byte load per predecessor
+    const double2 *lt2 = reinterpret_cast<const double2 *>(tab + P.o_lt_same);
     unsigned short *pt = ptr + (size_t)f0 * (size_t)(2 * nb);
     for (int64_t t = 0; t < T; t++) {
         // ---- observation column
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(VT_THREADS) void k_pyin_viterbi(const int64_t *__re
                         const bool ok = k >= 0 && k < nb;
                         const int kk = ok ? k : j;
                         const double pv = Vv[kk];
-                        const double same = lt(kk, ok ? e : 0, false), sw = lt(kk, ok ? e : 0, true);
+                        const double2 tt = lt2[((ok ? e : 0) + half) * nb + kk];
+                        const double same = tt.x, sw = tt.y;
                         const double c0v = pv + (v == 0 ? same : sw), c1v = pv + (v == 0 ? sw : same);
                         if (ok && c0v > b0) { b0 = c0v; i0 = v * nb + k; }
                         if (ok && c1v > b1) { b1 = c1v; i1 = v * nb + k; }
@@ -401,7 +403,7 @@ int pce_pyin_run(pce_ctx *c, const pce_pyin_plan *plan, const double *tables, in
         return pce_fail(c, PCE_E_LIMIT, "unsupported pYIN plan (frame_length 2048, max_period < 1024, n_pitch_bins <= 640, odd transition width)");
     const int W = 2 * P.half + 1;
     P.o_thr = 0; P.o_beta = P.o_thr + P.n_thr; P.o_bprefix = P.o_beta + P.n_thr; P.o_bfac = P.o_bprefix + P.n_thr + 1;
-    P.o_bexp = P.o_bfac + PY_MAXTR + 1; P.o_lt_same = P.o_bexp + PY_MAXTR + 1; P.o_lt_sw = P.o_lt_same + W * P.n_bins;
+    P.o_bexp = P.o_bfac + PY_MAXTR + 1; P.o_lt_same = (P.o_bexp + PY_MAXTR + 1 + 1) & ~1; P.o_lt_sw = P.o_lt_same + W * P.n_bins;   // (16-byte aligned pairs)
     const int64_t expect = (int64_t)P.o_lt_sw + (int64_t)W * P.n_bins;
     if (n_tables != expect) return pce_fail(c, PCE_E_INVALID, "pYIN table blob has %lld doubles, expected %lld", (long long)n_tables, (long long)expect);
     PCE_HIP(c, hipSetDevice(c->device));

@@ -77,7 +77,10 @@ def pyin_plan(sr, fmin=60.0, fmax=2000.0, frame_length=2048, hop_length=256, n_t
         return out
     lt_same = log_table(1 - switch_prob)
     lt_sw = log_table(switch_prob)
-    tables = np.concatenate([thresholds[1:], beta_probs, bprefix, bfac, bexp, lt_same.reshape(-1), lt_sw.reshape(-1)]).astype(np.float64)
+    head = np.concatenate([thresholds[1:], beta_probs, bprefix, bfac, bexp])
+    if len(head) % 2:                                            # the (same, switch) pairs are read as 16-byte values
+        head = np.concatenate([head, [0.0]])
+    tables = np.concatenate([head, np.stack([lt_same, lt_sw], axis=-1).reshape(-1)]).astype(np.float64)
     plan = PyinPlan(frame_length, hop_length, min_period, max_period, n_pitch_bins, width, n_thresholds, 0, float(sr), float(fmin),
                     float(12 * n_bins_per_semitone), float(no_trough_prob), float(np.log(_TINY)),
                     float(np.log(1.0 / (2 * n_pitch_bins) + _TINY)), float(_TINY))

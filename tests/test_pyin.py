@@ -45,7 +45,8 @@ def test_host_plan_tables_equal_the_dense_matrices():
         T = PO.transition_local_triangle(nb, W)
         full = np.log(np.kron(np.array([[0.99, 0.01], [0.01, 0.99]]), T) + PO.TINY64)
         o = 100 + 100 + 101 + 2 * (AA.MAX_TROUGHS + 1)
-        lt = tables[o:o + W * nb].reshape(W, nb); ls = tables[o + W * nb:].reshape(W, nb)
+        o += o % 2
+        pairs = tables[o:].reshape(W, nb, 2); lt = pairs[:, :, 0]; ls = pairs[:, :, 1]
         for e in range(-half, half + 1):
             ks = np.arange(max(0, -e), min(nb, nb - e))
             assert np.array_equal(lt[e + half, ks], full[ks, ks + e]) and np.array_equal(ls[e + half, ks], full[ks, nb + ks + e])
