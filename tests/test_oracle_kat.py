@@ -137,3 +137,20 @@ def test_pydub_and_praat_slicing_rules():
     ix1, ix2, x1 = O.praat_extract_part(n, rate, 0.25, 0.75)
     assert ix1 == 1 + math.ceil((0.25 - 0.5 / rate) * rate) and ix2 == 1 + math.floor((0.75 - 0.5 / rate) * rate)
     assert abs(x1 - (0.5 / rate + (ix1 - 1) / rate)) < 1e-15
+
+
+def test_stft_db_agrees_with_torch_stft():
+    """An independent implementation of the same conventions: torch.stft(center=True, pad_mode="constant",
+    periodic Hann) is documented to match librosa.stft's framing; the dB stage is amplitude_to_db(ref=max, top_db=80)."""
+    import torch
+    rng = np.random.default_rng(4)
+    t = np.arange(24000) / 16000.0
+    y = (0.3 * np.sin(2 * np.pi * 440 * t) * (t < 1.0) + 0.01 * rng.standard_normal(len(t))).astype(np.float32)
+    S = torch.stft(torch.from_numpy(y), 1024, 256, window=torch.hann_window(1024, periodic=True), center=True, pad_mode="constant",
+                   return_complex=True).abs().numpy()
+    want = 20 * np.log10(np.maximum(1e-5, S)) - 20 * np.log10(max(1e-5, S.max()))
+    want = np.maximum(want, want.max() - 80.0)
+    got = O.stft_db(y)
+    assert got.shape == want.shape == (513, 1 + len(y) // 256)
+    live = want > -79.0
+    assert np.max(np.abs(got[live] - want[live])) <= 2e-3
