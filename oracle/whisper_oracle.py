@@ -3,9 +3,14 @@
 torch (CPU, float32) restatement of openai-whisper==20240930's ``log_mel_spectrogram`` and
 ``AudioEncoder.forward`` (whisper/audio.py, whisper/model.py), the device work behind
 ``whisper_timestamped.transcribe`` (Code/Aligners/use_whisper_timestamped.py:139,150-163).
-**Parity unpinned**: openai-whisper is a third-party dependency absent from /root/reference and
-not installed here, and no checkpoint is available offline; the architecture is restated from
-its published definition and exercised with fixed-seed synthetic weights.
+openai-whisper is a third-party dependency absent from /root/reference and not installed here, and
+no checkpoint is available offline: the architecture is restated from its published definition and
+exercised with fixed-seed synthetic weights.  Pinned against an independent implementation of the
+same network: tests/golden/whisper_hf_tiny.npz holds log-mel columns, encoder rows, teacher-forced
+decoder logits and a cross-attention map produced by the installed transformers port
+(tests/golden/make_goldens_whisper_hf.py; tests/test_whisper_hf_crosscheck.py).  The stage of
+``find_alignment`` after the attention logits (normalise, median filter, mean, DTW) has no such
+check: parity unpinned.
 """
 import numpy as np
 import torch
@@ -133,7 +138,7 @@ def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
 
 
 def find_alignment(tokens, enc_out: np.ndarray, W: dict, dims: dict, num_frames: int, sot_len: int, head_mask=None,
-                   medfilt_width: int = 7, qk_scale: float = 1.0):
+                   medfilt_width: int = 7, qk_scale: float = 1.0, want_internal: bool = False):
     """TextDecoder.forward (teacher forced) + the cross-attention / DTW part of timing.py find_alignment.
     Returns (cost matrix fed to the DTW, text_indices, time_indices)."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
@@ -176,6 +181,10 @@ def find_alignment(tokens, enc_out: np.ndarray, W: dict, dims: dict, num_frames:
                 qks.append(qk[hh])
         h = F.layer_norm(x, (d,), t(W[p + "mlp_ln.weight"]), t(W[p + "mlp_ln.bias"]))
         x = x + F.linear(F.gelu(F.linear(h, t(W[p + "mlp.0.weight"]), t(W[p + "mlp.0.bias"]))), t(W[p + "mlp.2.weight"]), t(W[p + "mlp.2.bias"]))
+    if want_internal:                     # the teacher-forced decoder's own outputs (cross-checks against other implementations)
+        hidden = F.layer_norm(x, (d,), t(W["ln.weight"]), t(W["ln.bias"]))[0]
+        logits = (hidden @ t(W["token_embedding.weight"]).T).numpy()
+        return dict(hidden=hidden.numpy(), logits=logits, cross_qk=[q.numpy() for q in qks])
     weights = torch.stack(qks)[:, :, : num_frames // 2]
     weights = (weights * qk_scale).softmax(dim=-1)
     std, mean = torch.std_mean(weights, dim=-2, keepdim=True, unbiased=False)

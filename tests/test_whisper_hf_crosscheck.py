@@ -1,0 +1,36 @@
+"""The Whisper restatement (oracle/whisper_oracle.py: log-mel -> audio encoder -> teacher-forced text decoder with its
+cross-attention logits) against outputs of an independent implementation of the same network: the installed
+transformers WhisperForConditionalGeneration carrying the same fixed-seed weights (tests/golden/whisper_hf_tiny.npz,
+made by tests/golden/make_goldens_whisper_hf.py).  fp32 on both sides."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import whisper_oracle as WO
+from prosody_control_french_tts_amd import synth, whisper_weights as WW
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "whisper_hf_tiny.npz")
+
+
+def test_encoder_decoder_and_cross_attention_match_transformers():
+    g = np.load(GOLD)
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=77), WW.synthetic_decoder_weights(tdims, seed=78)
+    clip = synth.synth_clip(int(g["clip_index"][0]), seconds=float(g["seconds"][0]))
+    mel = WO.log_mel(clip, 80)
+    assert np.max(np.abs(mel[:, g["mel_cols"]] - g["hf_mel"])) <= 1e-5             # transformers' WhisperFeatureExtractor (observed: identical)
+    enc = WO.encoder_forward(mel, We, edims)
+    assert enc.shape == (1500, 128)
+    assert np.max(np.abs(enc[g["rows"]] - g["enc_rows"])) <= 2e-4, float(np.max(np.abs(enc[g["rows"]] - g["enc_rows"])))
+    tokens = g["tokens"].tolist()
+    hm = np.ones((2, 2), dtype=bool)
+    inner = WO.find_alignment(tokens, enc, Wd, tdims, 400, 3, head_mask=hm, want_internal=True)
+    assert inner["logits"].shape == g["logits"].shape == (len(tokens), 300)
+    assert np.max(np.abs(inner["logits"] - g["logits"])) <= 2e-3 * max(1.0, float(np.abs(g["logits"]).max()))
+    # cross-attention of layer 1, head 1: softmax over all 1500 frames of the restatement's logits
+    qk = torch.from_numpy(inner["cross_qk"][1 * 2 + 1])
+    att = torch.softmax(qk.float(), dim=-1).numpy()
+    assert att.shape == (len(tokens), 1500)
+    assert np.max(np.abs(att - g["cross_attn"].astype(np.float32))) <= 2e-3        # the fixture stores float16
