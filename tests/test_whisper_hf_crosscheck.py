@@ -34,3 +34,26 @@ def test_encoder_decoder_and_cross_attention_match_transformers():
     att = torch.softmax(qk.float(), dim=-1).numpy()
     assert att.shape == (len(tokens), 1500)
     assert np.max(np.abs(att - g["cross_attn"].astype(np.float32))) <= 2e-3        # the fixture stores float16
+
+
+def test_dtw_and_median_filter_match_transformers_ports():
+    """transformers carries ports of openai-whisper's ``dtw_cpu`` / ``backtrace`` and ``median_filter``
+    (generation_whisper._dynamic_time_warping, ._median_filter).  The restatement accumulates the DTW cost in float64,
+    those in float32 (as openai-whisper does): same paths on attention-like cost matrices and on exact ties."""
+    import transformers.models.whisper.generation_whisper as G
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        n, m = int(rng.integers(5, 40)), int(rng.integers(50, 300))
+        t = np.linspace(0, 1, m)[None, :]
+        c = np.sort(rng.uniform(0, 1, size=(n, 1)), axis=0)
+        x = -np.exp(-0.5 * ((t - c) / 0.03) ** 2) + 0.05 * rng.standard_normal((n, m))
+        ti, tj = WO.dtw_path(x)
+        hi, hj = G._dynamic_time_warping(x)
+        assert np.array_equal(ti, hi) and np.array_equal(tj, hj)
+    x = rng.integers(0, 3, size=(20, 55)).astype(np.float64)
+    ti, tj = WO.dtw_path(x)
+    hi, hj = G._dynamic_time_warping(x)
+    assert np.array_equal(ti, hi) and np.array_equal(tj, hj)
+    w = torch.randn(3, 4, 17, 40)
+    for width in (3, 7, 9):
+        assert torch.equal(WO.median_filter(w, width), G._median_filter(w, width))
