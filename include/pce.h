@@ -253,7 +253,8 @@ int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32
  * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on
  * (Code/Aligners/use_whisper_timestamped.py:163): x is `batch` row-major [n_rows][n_cols] fp64 cost matrices
  * (tokens x frames, n_rows <= 1024); path_i / path_j receive up to n_rows + n_cols index pairs per matrix
- * (stride n_rows + n_cols), path_len their count.  Indices are bit-identical to the CPU recurrence. */
+ * (stride n_rows + n_cols), path_len their count.  The accumulated cost is float32, as dtw_cpu keeps it (every cell the
+ * float64 sum of the input and the chosen predecessor, rounded to float32): indices bit-identical to that recurrence. */
 int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32_t batch, int32_t *path_i, int32_t *path_j,
             int32_t *path_len);
 

@@ -98,7 +98,7 @@ def dtw_path(x: np.ndarray):
     """openai-whisper timing.py ``dtw_cpu`` + ``backtrace`` (numba there, plain numpy loops here)."""
     x = np.asarray(x, dtype=np.float64)
     N, M = x.shape
-    cost = np.ones((N + 1, M + 1), dtype=np.float64) * np.inf
+    cost = np.ones((N + 1, M + 1), dtype=np.float32) * np.inf            # float32 there too: x + c is rounded at every cell
     trace = -np.ones((N + 1, M + 1), dtype=np.int64)
     cost[0, 0] = 0
     for j in range(1, M + 1):

@@ -24,31 +24,33 @@ __global__ __launch_bounds__(DTW_MAXN) void k_dtw(const double *__restrict__ x, 
                                                  const int *__restrict__ n_cols, int N_max, int M_max, unsigned char *__restrict__ trace,
                                                  int *__restrict__ path_i, int *__restrict__ path_j, int *__restrict__ path_len)
 {
-    __shared__ double diag[3][DTW_MAXN + 1];      // cost on diagonals d-2, d-1, d (index = row of the padded matrix)
+    // cost on diagonals d-2, d-1, d (index = row of the padded matrix), kept in float32 as openai-whisper's dtw_cpu keeps
+    // its cost array (np.float32): every cell is the float64 sum x + c rounded to float32, comparisons are on float32
+    __shared__ float diag[3][DTW_MAXN + 1];
     const int b = blockIdx.x, t = threadIdx.x;
     const int N = n_rows ? n_rows[b] : N_max, M = n_cols ? n_cols[b] : M_max;
     if (N <= 0 || M <= 0) { if (t == 0) path_len[b] = 0; return; }
     const double *xb = x + (size_t)b * (size_t)x_stride;
     unsigned char *tr = trace + (size_t)b * (size_t)(N_max + 1) * (size_t)(M_max + 1);
-    const double INF = __builtin_huge_val();
+    const float INF = __builtin_huge_valf();
     // padded cost matrix C[(N+1) x (M+1)]: C[0][0] = 0, rest of row 0 / column 0 = inf.
     // diagonal D (of the padded matrix) holds C[r][D - r]; thread t owns padded row r = t + 1.
     for (int r = t; r <= N; r += blockDim.x) { diag[0][r] = INF; diag[1][r] = INF; diag[2][r] = INF; }
     __syncthreads();
-    if (t == 0) diag[0][0] = 0.0;                 // diagonal 0: C[0][0]
+    if (t == 0) diag[0][0] = 0.0f;                // diagonal 0: C[0][0]
     // diagonal 1: C[0][1] = inf, C[1][0] = inf (already inf)
     __syncthreads();
     const int r = t + 1;
     for (int D = 2; D <= N + M; D++) {
-        double *cur = diag[D % 3]; const double *p1 = diag[(D - 1) % 3], *p2 = diag[(D - 2) % 3];
+        float *cur = diag[D % 3]; const float *p1 = diag[(D - 1) % 3], *p2 = diag[(D - 2) % 3];
         const int c = D - r;                      // padded column
         if (t < N && c >= 1 && c <= M) {
-            const double c0 = p2[r - 1], c1 = p1[r - 1], c2 = p1[r];      // C[r-1][c-1], C[r-1][c], C[r][c-1]
-            double cm; unsigned char tt;
+            const float c0 = p2[r - 1], c1 = p1[r - 1], c2 = p1[r];       // C[r-1][c-1], C[r-1][c], C[r][c-1]
+            float cm; unsigned char tt;
             if (c0 < c1 && c0 < c2) { cm = c0; tt = 0; }
             else if (c1 < c0 && c1 < c2) { cm = c1; tt = 1; }
             else { cm = c2; tt = 2; }
-            cur[r] = xb[(size_t)(r - 1) * ld + (c - 1)] + cm;
+            cur[r] = (float)(xb[(size_t)(r - 1) * ld + (c - 1)] + (double)cm);
             tr[(size_t)r * (M + 1) + c] = tt;
         } else if (t < N) {
             cur[r] = INF;

@@ -38,8 +38,8 @@ def test_encoder_decoder_and_cross_attention_match_transformers():
 
 def test_dtw_and_median_filter_match_transformers_ports():
     """transformers carries ports of openai-whisper's ``dtw_cpu`` / ``backtrace`` and ``median_filter``
-    (generation_whisper._dynamic_time_warping, ._median_filter).  The restatement accumulates the DTW cost in float64,
-    those in float32 (as openai-whisper does): same paths on attention-like cost matrices and on exact ties."""
+    (generation_whisper._dynamic_time_warping, ._median_filter): the cost array is float32 there, in the restatement and in
+    k_dtw alike (every cell the float64 sum rounded to float32): same paths, also on exact ties."""
     import transformers.models.whisper.generation_whisper as G
     rng = np.random.default_rng(0)
     for _ in range(12):
