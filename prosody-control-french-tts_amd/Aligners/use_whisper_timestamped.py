@@ -56,6 +56,35 @@ def json_to_textgrid(json_file, logger=None):
         return words_to_textgrid(json.load(f))
 
 
+TOKENS_PER_SECOND = 50          # openai-whisper audio.py: 20 ms per audio token
+
+
+def word_timings(text_indices, time_indices, words, word_token_counts):
+    """The tail of openai-whisper's ``find_alignment`` (timing.py): DTW path -> one (start, end) per word.
+
+    ``word_token_counts``: tokens per word for ``text_tokens + [eot]`` as ``tokenizer.split_to_word_tokens`` groups
+    them (the last group is the end-of-text token); ``words``: their texts, same length.  A token's time is the frame
+    at which the path first reaches it, a word runs from its first token's time to the next word's first token's time.
+    -> [{"text", "start", "end"}, ...] for every word but the final end-of-text group."""
+    import numpy as np
+    text_indices = np.asarray(text_indices); time_indices = np.asarray(time_indices)
+    jumps = np.pad(np.diff(text_indices), (1, 0), constant_values=1).astype(bool)
+    jump_times = time_indices[jumps] / TOKENS_PER_SECOND
+    counts = list(word_token_counts)
+    boundaries = np.pad(np.cumsum(counts[:-1]), (1, 0))
+    starts, ends = jump_times[boundaries[:-1]], jump_times[boundaries[1:]]
+    return [{"text": w, "start": float(a), "end": float(b)} for w, a, b in zip(words, starts, ends)]
+
+
+def transcription_result(word_items, language="fr"):
+    """Word timings -> the dict shape of ``whisper_timestamped.transcribe`` that ``json_to_textgrid`` and the rest of the
+    pipeline read (Code/Aligners/use_whisper_timestamped.py:244-261, 330-395): one segment holding the words."""
+    words = [{"text": w["text"], "start": round(w["start"], 2), "end": round(w["end"], 2), "confidence": w.get("confidence", 1.0)} for w in word_items]
+    text = "".join(w["text"] for w in word_items).strip()
+    seg = {"id": 0, "start": words[0]["start"] if words else 0.0, "end": words[-1]["end"] if words else 0.0, "text": text, "words": words}
+    return {"text": text, "segments": [seg] if words else [], "language": language}
+
+
 def main(audio_path, out_path, whisper_model="medium", device=None, logger=None):
     raise NotImplementedError("free-running Whisper transcription (checkpoint + tokenizer) is not available in this build; the gate, "
                               "resampler, log-mel, encoder and token-level forced alignment (ProsodyEngine.whisper_align) are")

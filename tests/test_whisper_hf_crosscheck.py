@@ -57,3 +57,16 @@ def test_dtw_and_median_filter_match_transformers_ports():
     w = torch.randn(3, 4, 17, 40)
     for width in (3, 7, 9):
         assert torch.equal(WO.median_filter(w, width), G._median_filter(w, width))
+
+
+def test_word_timings_follow_the_first_arrival_rule():
+    from prosody_control_french_tts_amd.Aligners import use_whisper_timestamped as UW
+    ti = [0, 0, 1, 1, 1, 2, 3, 3]; tj = [0, 1, 2, 3, 4, 5, 6, 7]
+    got = UW.word_timings(ti, tj, [" bon", " jour", ""], [2, 1, 1])
+    assert got == [{"text": " bon", "start": 0.0, "end": 0.1}, {"text": " jour", "start": 0.1, "end": 0.12}]
+    res = UW.transcription_result(got)
+    assert res["text"] == "bon jour" and [w["text"] for w in res["segments"][0]["words"]] == [" bon", " jour"]
+    assert UW.transcription_result([]) == {"text": "", "segments": [], "language": "fr"}
+    # the same first-arrival times from transformers' port of the token-level rule (generation_whisper: jumps / jump_times)
+    jumps = np.pad(np.diff(np.array(ti)), (1, 0), constant_values=1).astype(bool)
+    assert np.array_equal(np.array(tj)[jumps], [0, 2, 5, 6])
