@@ -195,3 +195,51 @@ def find_alignment(tokens, enc_out: np.ndarray, W: dict, dims: dict, num_frames:
     cost = (-matrix).double().numpy()
     ti, tj = dtw_path(cost)
     return cost, ti, tj
+
+
+def apply_decoding_rules(logits: np.ndarray, tokens, sample_begin: int, rules: dict) -> np.ndarray:
+    """openai-whisper decoding.py logit filters of a default ``DecodingTask`` at temperature 0, in its order:
+    SuppressBlank, SuppressTokens, ApplyTimestampRules.  ``logits``: float32 [n_vocab] of the last position;
+    ``tokens``: the sequence so far (prompt included).  rules: eot, no_timestamps, timestamp_begin, suppress_tokens,
+    blank_tokens (the ids of " " and eot), max_initial_timestamp_index."""
+    x = torch.from_numpy(np.array(logits, dtype=np.float32))
+    eot, tsb = rules["eot"], rules["timestamp_begin"]
+    if len(tokens) == sample_begin:
+        x[list(rules["blank_tokens"])] = -np.inf
+    x[list(rules["suppress_tokens"])] = -np.inf
+    x[rules["no_timestamps"]] = -np.inf
+    seq = list(tokens[sample_begin:])
+    last_ts = len(seq) >= 1 and seq[-1] >= tsb
+    pen_ts = len(seq) < 2 or seq[-2] >= tsb
+    if last_ts:
+        if pen_ts:
+            x[tsb:] = -np.inf
+        else:
+            x[:eot] = -np.inf
+    stamps = [t for t in seq if t >= tsb]
+    if stamps:
+        last = stamps[-1] if (last_ts and not pen_ts) else stamps[-1] + 1
+        x[tsb:last] = -np.inf
+    if len(tokens) == sample_begin:
+        x[:tsb] = -np.inf
+        if rules.get("max_initial_timestamp_index") is not None:
+            x[tsb + rules["max_initial_timestamp_index"] + 1:] = -np.inf
+    logprobs = F.log_softmax(x.float(), dim=-1)
+    if logprobs[tsb:].logsumexp(dim=-1) > logprobs[:tsb].max():
+        x[:tsb] = -np.inf
+    return x.numpy()
+
+
+def greedy_decode(enc_out: np.ndarray, W: dict, dims: dict, initial_tokens, rules: dict, sample_len: int):
+    """``DecodingTask._main_loop`` with a ``GreedyDecoder`` at temperature 0 for one utterance: arg-max of the filtered
+    logits until end-of-text or ``sample_len`` new tokens.  -> the full token list (prompt included)."""
+    tokens = list(initial_tokens)
+    sample_begin = len(tokens)
+    for _ in range(sample_len):
+        logits = find_alignment(tokens, enc_out, W, dims, 2, 0, want_internal=True)["logits"][-1]
+        nxt = int(np.argmax(apply_decoding_rules(logits, tokens, sample_begin, rules)))
+        tokens.append(nxt)
+        if nxt == rules["eot"]:
+            break
+    return tokens
+

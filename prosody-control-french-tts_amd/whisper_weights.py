@@ -96,3 +96,18 @@ def synthetic_decoder_weights(dims, seed=448):
 
 def pack_decoder(W, dims) -> np.ndarray:
     return np.concatenate([np.asarray(W[name], dtype=np.float32).reshape(-1) for name, _ in decoder_tensor_order(dims)])
+
+
+def greedy_test_decoder_weights(dims, seed=79):
+    """Synthetic decoder weights for free-running decoding tests: with the usual initialisation the tied output
+    projection makes the decoder repeat its input token for ever; small token embeddings and stronger cross-attention
+    values let position and audio decide, so that the decoding rules (timestamps, suppression, end of text) get exercised."""
+    W = synthetic_decoder_weights(dims, seed)
+    rng = np.random.default_rng(seed + 1000)
+    W["token_embedding.weight"] = (0.08 * rng.standard_normal(W["token_embedding.weight"].shape)).astype(np.float32)
+    W["positional_embedding"] = (0.6 * rng.standard_normal(W["positional_embedding"].shape)).astype(np.float32)
+    for name in W:
+        if "cross_attn.value.weight" in name or "cross_attn.out.weight" in name:
+            W[name] = (W[name] * 2.5).astype(np.float32)
+    return W
+

@@ -70,3 +70,29 @@ def test_word_timings_follow_the_first_arrival_rule():
     # the same first-arrival times from transformers' port of the token-level rule (generation_whisper: jumps / jump_times)
     jumps = np.pad(np.diff(np.array(ti)), (1, 0), constant_values=1).astype(bool)
     assert np.array_equal(np.array(tj)[jumps], [0, 2, 5, 6])
+
+
+def _greedy_gold():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "whisper_greedy_tiny.npz"))
+    eot, no_ts, tsb, mi = (int(v) for v in g["layout"])
+    rules = dict(eot=eot, no_timestamps=no_ts, timestamp_begin=tsb, suppress_tokens=g["suppress"].tolist(), blank_tokens=g["blank"].tolist(),
+                 max_initial_timestamp_index=mi)
+    return g, rules
+
+
+def test_greedy_decoding_matches_transformers_model_and_logit_processors():
+    """Free-running decoding at temperature 0: the restatement of openai-whisper's DecodingTask loop and logit filters
+    against token sequences produced by the installed transformers model driven through transformers' own ports of those
+    filters (tests/golden/make_goldens_whisper_greedy.py): timestamps in pairs, monotone, text in between."""
+    g, rules = _greedy_gold()
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=77), WW.greedy_test_decoder_weights(tdims, seed=79)
+    for ci in g["clips"]:
+        clip = synth.synth_clip(int(ci), seconds=4.0)
+        enc = WO.encoder_forward(WO.log_mel(clip, 80), We, edims)
+        want = g[f"tokens_{int(ci)}"].tolist()
+        got = WO.greedy_decode(enc, Wd, tdims, g["initial"].tolist(), rules, sample_len=len(want) - len(g["initial"]))
+        assert got == want, (int(ci), got, want)
+        new = want[len(g["initial"]):]
+        assert new[0] >= rules["timestamp_begin"] and any(t < rules["eot"] for t in new)
