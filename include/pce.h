@@ -249,6 +249,20 @@ int pce_whisper_align_shape(pce_ctx *ctx, int32_t clip, int32_t *n_rows, int32_t
 /* path arrays hold up to n_rows + n_cols entries; cost (nullable) is the [n_rows][n_cols] fp64 DTW input */
 int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32_t *time_idx, int32_t *path_len, double *cost);
 
+/* ---- R8: free-running decoding, one step -------------------------------------
+ * openai-whisper decoding.py at temperature 0 (a default DecodingTask with a GreedyDecoder, what whisper_timestamped's
+ * transcribe runs first: Code/Aligners/use_whisper_timestamped.py:150-163): the text decoder over the sequences so far,
+ * the logits of the last position through the tied output projection, the logit filters SuppressBlank / SuppressTokens /
+ * ApplyTimestampRules and the arg-max (first maximum; a sequence whose last token is end-of-text stays there).
+ * vocab_mask[n_vocab]: bit 0 = always suppressed (the suppress list and <|notimestamps|>), bit 1 = suppressed at the
+ * first sampled position (the blank token and end-of-text).  The prompt (<|startoftranscript|><|fr|><|transcribe|>),
+ * the loop and the stopping rule are host logic (Aligners/decoding.py); token ids in, token ids out (text needs the
+ * checkpoint's vocabulary).  The cross-attention K / V of all layers are computed at the first step after
+ * pce_whisper_encode_run and kept. */
+typedef struct pce_whisper_decode_rules { int32_t eot, timestamp_begin, max_initial_timestamp_index /* < 0: none */, reserved; } pce_whisper_decode_rules;
+int pce_whisper_decode_step(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets /* [clips + 1] */, int32_t sample_begin,
+                            const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens /* [clips] */);
+
 /* ---- R8: dynamic time warping (alignment indices) ------------------------
  * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on
  * (Code/Aligners/use_whisper_timestamped.py:163): x is `batch` row-major [n_rows][n_cols] fp64 cost matrices
@@ -300,7 +314,7 @@ enum pce_kernel_id {
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
     PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN, PCE_K_NW, PCE_K_STFT_NORM,
-    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_COUNT
+    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_WHISPER_DECODE, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

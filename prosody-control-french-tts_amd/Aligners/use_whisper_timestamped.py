@@ -3,8 +3,9 @@ inline copy :581-599) on the GPU, plus the JSON -> TextGrid conversion of :330-3
 
 What runs on the engine: the gate, the 16 kHz resampler, log-mel, the audio encoder and the forced
 alignment of *given* token ids (teacher-forced text decoder, alignment-head cross-attention, DTW:
-``ProsodyEngine.whisper_align``).  Free-running transcription needs the trained checkpoint and the
-tokenizer vocabulary, neither of which is available offline, so ``main()`` raises ``NotImplementedError``."""
+``ProsodyEngine.whisper_align``), free-running greedy decoding at token level (``Aligners/decoding.py``).  Turning
+audio files into TextGrids end to end additionally needs the trained checkpoint and the tiktoken vocabulary, neither of
+which is available offline, so ``main()`` raises ``NotImplementedError``."""
 import os
 
 from .. import hostrules as H

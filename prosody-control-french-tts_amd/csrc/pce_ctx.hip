@@ -326,7 +326,7 @@ const char *pce_kernel_name(int id)
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
-        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi"};
+        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -781,6 +781,97 @@ __global__ void k_embed_tokens(const int *__restrict__ tokens /* [clips][T_pad] 
     out[i] = tok_emb[(int64_t)tokens[m] * d + col] + pos_emb[(int64_t)t * d + col];
 }
 
+// last position of every sequence: resid row (clip * T_pad + len - 1) -> out row clip
+__global__ void k_gather_last(const float *__restrict__ resid, const int *__restrict__ t_len, int T_pad, int d, int n, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * d) return;
+    const int clip = (int)(i / d), col = (int)(i - (int64_t)clip * d);
+    out[i] = resid[((int64_t)clip * T_pad + t_len[clip] - 1) * d + col];
+}
+
+// openai-whisper decoding.py at temperature 0, one workgroup per sequence: SuppressBlank, SuppressTokens,
+// ApplyTimestampRules on the logits of the last position, then the GreedyDecoder's arg-max (first maximum) and its
+// "once end-of-text, always end-of-text" rule.  vmask: bit 0 = always suppressed (suppress list, no_timestamps),
+// bit 1 = suppressed at the first sampled position (blank, end of text).
+struct DecRules { int eot, ts_begin, n_vocab, ld, sample_begin, max_initial_ts; };
+__global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits, const int *__restrict__ tokens, const int *__restrict__ t_len,
+                                                     int T_pad, const unsigned char *__restrict__ vmask, DecRules R, int *__restrict__ next)
+{
+    __shared__ float r_f[2][4]; __shared__ int r_i[4]; __shared__ float s_bcast[2]; __shared__ int s_flags[4];
+    const int clip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int L = t_len[clip];
+    const int *seq = tokens + (size_t)clip * T_pad;
+    float *x = logits + (size_t)clip * R.ld;
+    if (tid == 0) {
+        const int ns = L - R.sample_begin;                         // sampled tokens so far
+        const bool last_ts = ns >= 1 && seq[L - 1] >= R.ts_begin;
+        const bool pen_ts = ns < 2 || seq[L - 2] >= R.ts_begin;
+        int last_stamp = -1;
+        for (int t = R.sample_begin; t < L; t++) if (seq[t] >= R.ts_begin) last_stamp = seq[t];
+        int ts_floor = R.ts_begin;                                 // timestamps below this are forbidden
+        if (last_stamp >= 0) ts_floor = (last_ts && !pen_ts) ? last_stamp : last_stamp + 1;
+        s_flags[0] = last_ts ? (pen_ts ? 1 : 2) : 0;               // 1: no timestamp may follow, 2: no text token may follow
+        s_flags[1] = ts_floor;
+        s_flags[2] = ns == 0;
+        s_flags[3] = L > 0 && seq[L - 1] == R.eot;
+    }
+    __syncthreads();
+    const int pair = s_flags[0], ts_floor = s_flags[1]; const bool first = s_flags[2] != 0, done = s_flags[3] != 0;
+    const float NEG = -__builtin_huge_valf();
+    // pass 1: masks; maximum over the text ids and over the timestamp ids
+    float m_text = NEG, m_ts = NEG;
+    for (int v = tid; v < R.n_vocab; v += 256) {
+        float a = x[v];
+        const unsigned char mk = vmask[v];
+        bool off = (mk & 1) || (first && (mk & 2));
+        if (pair == 1 && v >= R.ts_begin) off = true;
+        if (pair == 2 && v < R.eot) off = true;
+        if (v >= R.ts_begin && v < ts_floor) off = true;
+        if (first && (v < R.ts_begin || (R.max_initial_ts >= 0 && v > R.ts_begin + R.max_initial_ts))) off = true;
+        if (off) a = NEG;
+        x[v] = a;
+        if (v < R.ts_begin) m_text = fmaxf(m_text, a); else m_ts = fmaxf(m_ts, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) { m_text = fmaxf(m_text, __shfl_xor(m_text, o, 64)); m_ts = fmaxf(m_ts, __shfl_xor(m_ts, o, 64)); }
+    if (lane == 0) { r_f[0][wv] = m_text; r_f[1][wv] = m_ts; }
+    __syncthreads();
+    m_text = fmaxf(fmaxf(r_f[0][0], r_f[0][1]), fmaxf(r_f[0][2], r_f[0][3]));
+    m_ts = fmaxf(fmaxf(r_f[1][0], r_f[1][1]), fmaxf(r_f[1][2], r_f[1][3]));
+    __syncthreads();
+    // pass 2: log-sum-exp over the timestamps; "if the probability mass of the timestamps exceeds every text token, sample a timestamp"
+    float se = 0.f;
+    if (m_ts > NEG)
+        for (int v = R.ts_begin + tid; v < R.n_vocab; v += 256) se += __expf(x[v] - m_ts);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (lane == 0) r_f[0][wv] = se;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (r_f[0][0] + r_f[0][1]) + (r_f[0][2] + r_f[0][3]);
+        const float lse_ts = m_ts > NEG ? m_ts + __logf(tot) : NEG;
+        s_bcast[0] = (lse_ts > m_text) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const bool only_ts = s_bcast[0] != 0.f;
+    // pass 3: arg-max (first maximum)
+    float best = NEG; int bi = 0x7fffffff;
+    for (int v = (only_ts ? R.ts_begin : 0) + tid; v < R.n_vocab; v += 256) {
+        const float a = x[v];
+        if (a > best) { best = a; bi = v; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { r_f[0][wv] = best; r_i[wv] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int u = 1; u < 4; u++) if (r_f[0][u] > best || (r_f[0][u] == best && r_i[u] < bi)) { best = r_f[0][u]; bi = r_i[u]; }
+        if (bi == 0x7fffffff) bi = only_ts ? R.ts_begin : 0;       // every candidate is -inf: torch.argmax returns the first index
+        next[clip] = done ? R.eot : bi;
+    }
+}
+
 // BERT embeddings: word[id] + token_type[0] + position[t] (the LayerNorm follows as its own launch)
 __global__ void k_bert_embed(const int *__restrict__ tokens /* [seqs][T_pad] */, const float *__restrict__ word, const float *__restrict__ pos,
                              const float *__restrict__ type0, int T_pad, int n_pos, int d, int64_t rows, float *__restrict__ out)
@@ -992,6 +1083,9 @@ struct WhisperState {
     bool dec_loaded = false;
     DevBuf dw_bf16, dw_f32, d_tok_emb, d_pos_emb;
     DevBuf d_tab, d_tokens, d_resid, d_ln, d_qk, d_vt, d_attn, d_q, d_hidden, d_enc_bf16, d_aw, d_cost, d_trace, d_pi, d_pj, d_pl, d_heads;
+    // free-running decoding: tied output projection in bf16 (rows padded to 128), cross K / V of every layer, last-position buffers
+    DevBuf g_emb_bf16, g_xk, g_xvt, g_last, g_lastln, g_logits, g_mask, g_next;
+    int g_xkv_clips = -1;            // clips the cross K / V cache was computed for (-1: stale)
     struct DLayer { size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, lnx_w, lnx_b, xq_w, xq_b, xkv_w, xkv_b, xout_w, xout_b,
                     ln2_w, ln2_b, m1_w, m1_b, m2_w, m2_b; };
     std::vector<DLayer> dlayers;
@@ -1128,6 +1222,7 @@ void pce_whisper_free(pce_ctx *c)
                       &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
                       &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
+                      &w->g_emb_bf16, &w->g_xk, &w->g_xvt, &w->g_last, &w->g_lastln, &w->g_logits, &w->g_mask, &w->g_next,
                       &w->bert.w_bf16, &w->bert.w_f32, &w->bert.word, &w->bert.pos, &w->bert.type0, &w->bert.tab, &w->bert.tokens, &w->bert.resid,
                       &w->bert.ln, &w->bert.qk, &w->bert.vt, &w->bert.attn, &w->bert.hidden, &w->bert.logits};
     for (auto b : bufs) b->release();
@@ -1331,7 +1426,7 @@ int pce_whisper_encode_run(pce_ctx *c)
     hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + w->lnp_w,
                        Wf + w->lnp_b, M, d, w->final_out.as<float>());
     PCE_HIP(c, hipGetLastError());
-    w->n_clips_enc = n;
+    w->n_clips_enc = n; w->g_xkv_clips = -1;
     return PCE_OK;
 }
 
@@ -1411,9 +1506,16 @@ int pce_whisper_decoder_load(pce_ctx *c, const pce_whisper_text_dims *dims, cons
     PCE_HIP(c, hipMemcpyAsync(w->d_pos_emb.p, pos, sizeof(float) * (size_t)TC * d, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up((int64_t)mats.size(), 256)), dim3(256), 0, c->stream, tmp.as<float>(),
                        w->dw_bf16.as<bf16>(), (int64_t)mats.size());
+    {   // tied output projection for free-running decoding: the token embedding in bf16, rows padded to the 128-column GEMM tile
+        const size_t Vp = (size_t)div_up(V, 128) * 128;
+        PCE_HIP(c, w->g_emb_bf16.reserve(sizeof(bf16) * Vp * (size_t)d + 256));
+        PCE_HIP(c, hipMemsetAsync(w->g_emb_bf16.p, 0, sizeof(bf16) * Vp * (size_t)d, c->stream));
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up((int64_t)V * d, 256)), dim3(256), 0, c->stream, w->d_tok_emb.as<float>(),
+                           w->g_emb_bf16.as<bf16>(), (int64_t)V * d);
+    }
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     tmp.release();
-    w->dec_loaded = true;
+    w->dec_loaded = true; w->g_xkv_clips = -1;
     return PCE_OK;
 }
 
@@ -1591,6 +1693,129 @@ int pce_whisper_align_shape(pce_ctx *c, int32_t clip, int32_t *n_rows, int32_t *
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// Free-running decoding, one step: the text decoder over the sequences so far (cross K / V of every layer computed once
+// per encoded batch and kept), logits of the last position through the tied output projection, openai-whisper's logit
+// filters and greedy choice.  The loop over steps, the prompt and the stopping rule are host logic
+// (Aligners/decoding.py); every step re-runs the decoder over the whole prefix (a per-step K / V cache for the
+// self-attention is the next refinement).
+// ---------------------------------------------------------------------------
+extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, int32_t sample_begin,
+                                       const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens)
+{
+    if (!c || !tokens || !token_offsets || !rules || !vocab_mask || !next_tokens) return PCE_E_INVALID;
+    WhisperState *w = ws_of(c);
+    if (!w->dec_loaded) return pce_fail(c, PCE_E_STATE, "pce_whisper_decode_step before pce_whisper_decoder_load");
+    if (w->n_clips_enc < 0) return pce_fail(c, PCE_E_STATE, "run pce_whisper_encode_run first");
+    if (w->tdims.n_state != w->dims.n_state) return pce_fail(c, PCE_E_INVALID, "decoder and encoder widths differ");
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int n = w->n_clips_enc, d = w->tdims.n_state, H = w->tdims.n_head, L = w->tdims.n_layer, V = w->tdims.n_vocab, SPD = 512;
+    if (rules->eot < 0 || rules->eot >= V || rules->timestamp_begin <= rules->eot || rules->timestamp_begin > V || sample_begin < 1)
+        return pce_fail(c, PCE_E_INVALID, "decoding rules: need 0 <= eot < timestamp_begin <= n_vocab, sample_begin >= 1");
+    int T_max = 0;
+    std::vector<int> t_len((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const int T = token_offsets[i + 1] - token_offsets[i];
+        if (T < sample_begin || T > w->tdims.n_text_ctx) return pce_fail(c, PCE_E_INVALID, "clip %d: %d tokens (need %d..%d)", i, T, sample_begin, w->tdims.n_text_ctx);
+        t_len[(size_t)i] = T; T_max = std::max(T_max, T);
+    }
+    const int T_pad = (int)div_up(T_max, 64) * 64;
+    const int64_t Mt = (int64_t)n * T_pad, Ma = (int64_t)n * W_CTX;
+    const int64_t Vp = div_up(V, 128) * 128;
+    std::vector<int> tab((size_t)4 * n), tok((size_t)Mt, 0);
+    for (int i = 0; i < n; i++) {
+        tab[(size_t)i] = i * T_pad; tab[(size_t)n + i] = t_len[(size_t)i]; tab[(size_t)2 * n + i] = i * W_CTX; tab[(size_t)3 * n + i] = W_CTX;
+        for (int t = 0; t < t_len[(size_t)i]; t++) {
+            const int v = tokens[token_offsets[i] + t];
+            if (v < 0 || v >= V) return pce_fail(c, PCE_E_INVALID, "token %d out of the vocabulary", v);
+            tok[(size_t)i * T_pad + t] = v;
+        }
+    }
+    PCE_HIP(c, w->d_tab.reserve(sizeof(int) * tab.size()));
+    PCE_HIP(c, w->d_tokens.reserve(sizeof(int) * tok.size()));
+    PCE_HIP(c, w->d_resid.reserve(sizeof(float) * (size_t)Mt * d));
+    PCE_HIP(c, w->d_ln.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    PCE_HIP(c, w->d_qk.reserve(sizeof(bf16) * (size_t)Mt * 2 * d + 4096));
+    PCE_HIP(c, w->d_attn.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    PCE_HIP(c, w->d_q.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
+    PCE_HIP(c, w->d_hidden.reserve(sizeof(bf16) * (size_t)Mt * 4 * d + 4096));
+    const size_t dvt_elems = (size_t)n * (size_t)d * SPD + 64;
+    PCE_HIP(c, w->d_vt.reserve(sizeof(bf16) * dvt_elems));
+    PCE_HIP(c, w->g_last.reserve(sizeof(float) * (size_t)n * d));
+    PCE_HIP(c, w->g_lastln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+    PCE_HIP(c, w->g_logits.reserve(sizeof(float) * (size_t)n * (size_t)Vp));
+    PCE_HIP(c, w->g_mask.reserve((size_t)V + 64));
+    PCE_HIP(c, w->g_next.reserve(sizeof(int) * (size_t)n));
+    PCE_HIP(c, hipMemcpyAsync(w->d_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->d_tokens.p, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->g_mask.p, vocab_mask, (size_t)V, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    const int *T0 = w->d_tab.as<int>(), *TL = T0 + n, *A0 = T0 + 2 * n, *AL = T0 + 3 * n;
+    const bf16 *Wb = w->dw_bf16.as<bf16>();
+    const float *Wf = w->dw_f32.as<float>();
+    KernelTimer timer(c, PCE_K_WHISPER_DECODE);
+    // ---- cross K / V of every layer, once per encoded batch
+    const size_t xk_l = (size_t)Ma * d, xvt_l = (size_t)n * (size_t)d * AT_SP;
+    if (w->g_xkv_clips != n) {
+        PCE_HIP(c, w->g_xk.reserve(sizeof(bf16) * xk_l * (size_t)L + 4096));
+        PCE_HIP(c, w->g_xvt.reserve(sizeof(bf16) * xvt_l * (size_t)L + 4096));
+        PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)Ma * d + 4096));
+        PCE_HIP(c, hipMemsetAsync(w->g_xvt.p, 0, sizeof(bf16) * xvt_l * (size_t)L, c->stream));      // V^T columns 1500..AT_SP are read as zeros
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up(Ma * d, 256)), dim3(256), 0, c->stream, w->final_out.as<float>(),
+                           w->d_enc_bf16.as<bf16>(), Ma * d);
+        for (int l = 0; l < L; l++) {
+            const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
+            launch_gemm<EPI_QKV>(c, w->d_enc_bf16.as<bf16>(), d, 0, Wb + ly.xkv_w, (int)Ma, 2 * d, d, Wf + ly.xkv_b, w->g_xk.as<bf16>() + xk_l * (size_t)l, d, 0, 1,
+                                 reinterpret_cast<const float *>(w->g_xvt.as<bf16>() + xvt_l * (size_t)l), W_CTX, d, AT_SP);
+        }
+        w->g_xkv_clips = n;
+    }
+    PCE_HIP(c, hipMemsetAsync(w->d_attn.p, 0, sizeof(bf16) * (size_t)Mt * d + 4096, c->stream));      // pad rows: no stale bits (see pce_whisper_align_run)
+    PCE_HIP(c, hipMemsetAsync(w->d_vt.p, 0, sizeof(bf16) * dvt_elems, c->stream));
+    hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)div_up(Mt * d, 256)), dim3(256), 0, c->stream, w->d_tokens.as<int>(),
+                       w->d_tok_emb.as<float>(), w->d_pos_emb.as<float>(), T_pad, w->tdims.n_text_ctx, d, Mt, w->d_resid.as<float>());
+    auto attn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp,
+                    const int *k0, const int *kl, int causal) {
+        AttnArgs a{};
+        a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
+        a.q_row0 = T0; a.q_len = TL; a.k_row0 = k0; a.k_len = kl; a.out = w->d_attn.as<bf16>(); a.out_ld = d; a.causal = causal;
+        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+    };
+    auto ln = [&](size_t w_off, size_t b_off) {
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(Mt, 4)), dim3(256), 0, c->stream, w->d_resid.as<float>(), Wf + w_off, Wf + b_off,
+                           Mt, d, w->d_ln.as<bf16>());
+    };
+    for (int l = 0; l < L; l++) {
+        const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
+        ln(ly.ln1_w, ly.ln1_b);
+        launch_gemm<EPI_QKV>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)Mt, 3 * d, d, Wf + ly.qkv_b, w->d_qk.as<bf16>(), 2 * d, 0, 1,
+                             reinterpret_cast<const float *>(w->d_vt.as<bf16>()), T_pad, 2 * d, SPD);
+        attn(w->d_qk.as<bf16>(), 2 * d, w->d_qk.as<bf16>() + d, 2 * d, w->d_vt.as<bf16>(), (int64_t)d * SPD, SPD, T0, TL, 1);
+        launch_gemm<EPI_RESID_F32>(c, w->d_attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)Mt, d, d, Wf + ly.out_b, w->d_resid.as<float>(), d, 0, 1);
+        ln(ly.lnx_w, ly.lnx_b);
+        launch_gemm<EPI_BF16>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.xq_w, (int)Mt, d, d, Wf + ly.xq_b, w->d_q.as<bf16>(), d, 0, 1);
+        attn(w->d_q.as<bf16>(), d, w->g_xk.as<bf16>() + xk_l * (size_t)l, d, w->g_xvt.as<bf16>() + xvt_l * (size_t)l, (int64_t)d * AT_SP, AT_SP, A0, AL, 0);
+        launch_gemm<EPI_RESID_F32>(c, w->d_attn.as<bf16>(), d, 0, Wb + ly.xout_w, (int)Mt, d, d, Wf + ly.xout_b, w->d_resid.as<float>(), d, 0, 1);
+        ln(ly.ln2_w, ly.ln2_b);
+        launch_gemm<EPI_GELU_BF16>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.m1_w, (int)Mt, 4 * d, d, Wf + ly.m1_b, w->d_hidden.as<bf16>(), 4 * d, 0, 1);
+        launch_gemm<EPI_RESID_F32>(c, w->d_hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, (int)Mt, d, 4 * d, Wf + ly.m2_b, w->d_resid.as<float>(), d, 0, 1);
+    }
+    // ---- last position -> ln -> logits = hidden . E^T (fp32, zero-initialised accumulator)
+    hipLaunchKernelGGL(k_gather_last, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, w->d_resid.as<float>(), TL, T_pad, d, n,
+                       w->g_last.as<float>());
+    hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_last.as<float>(), Wf + w->dln_w, Wf + w->dln_b,
+                       (int64_t)n, d, w->g_lastln.as<bf16>());
+    PCE_HIP(c, hipMemsetAsync(w->g_logits.p, 0, sizeof(float) * (size_t)n * (size_t)Vp, c->stream));
+    launch_gemm<EPI_RESID_F32>(c, w->g_lastln.as<bf16>(), d, 0, w->g_emb_bf16.as<bf16>(), n, (int)Vp, d, nullptr, w->g_logits.as<float>(), Vp, 0, 1);
+    DecRules R{rules->eot, rules->timestamp_begin, V, (int)Vp, sample_begin, rules->max_initial_timestamp_index};
+    hipLaunchKernelGGL(k_decode_rules, dim3((unsigned)n), dim3(256), 0, c->stream, w->g_logits.as<float>(), w->d_tokens.as<int>(), TL, T_pad,
+                       w->g_mask.as<unsigned char>(), R, w->g_next.as<int>());
+    PCE_HIP(c, hipGetLastError());
+    PCE_HIP(c, hipMemcpyAsync(next_tokens, w->g_next.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    return PCE_OK;
+}
 
 // ---------------------------------------------------------------------------
 // Break-prediction token classifier: BertForTokenClassification forward (post-LN encoder layers on the same GEMM /

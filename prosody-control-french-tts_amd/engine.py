@@ -70,6 +70,10 @@ class WhisperTextDims(C.Structure):
     _fields_ = [("n_vocab", C.c_int32), ("n_text_ctx", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32)]
 
 
+class WhisperDecodeRules(C.Structure):
+    _fields_ = [("eot", C.c_int32), ("timestamp_begin", C.c_int32), ("max_initial_timestamp_index", C.c_int32), ("reserved", C.c_int32)]
+
+
 class BertDims(C.Structure):
     _fields_ = [("n_vocab", C.c_int32), ("n_pos", C.c_int32), ("n_type", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32),
                 ("n_layer", C.c_int32), ("n_labels", C.c_int32)]
@@ -86,7 +90,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -96,7 +100,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch",
+           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step",
            "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
@@ -143,6 +147,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_decoder_load.argtypes = [vp, C.POINTER(WhisperTextDims), vp, i64]
     lib.pce_whisper_align_run.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_float]
     lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.pce_whisper_decode_step.argtypes = [vp, vp, vp, i32, C.POINTER(WhisperDecodeRules), vp, vp]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
@@ -375,6 +380,10 @@ class ProsodyEngine:
 
     def whisper_encode_run(self):
         self._check(self._lib.pce_whisper_encode_run(self._ctx))
+        self._n_encoded = len(self.clip_lengths)
+
+    def whisper_num_encoded(self) -> int:
+        return getattr(self, "_n_encoded", 0)
 
     def whisper_encode_fetch(self, clip: int) -> np.ndarray:
         out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)
@@ -441,6 +450,18 @@ class ProsodyEngine:
         ss = np.zeros(nf.value, dtype=np.int64); cnt = np.zeros(nf.value, dtype=np.int32)
         self._check(self._lib.pce_frame_energy_fetch(self._ctx, int(clip), ss.ctypes.data, cnt.ctypes.data))
         return ss, cnt
+
+    def whisper_decode_step(self, token_lists, sample_begin: int, eot: int, timestamp_begin: int, vocab_mask, max_initial_timestamp_index=None):
+        """One step of free-running decoding for every encoded clip -> next token ids (int32 [clips]).  ``vocab_mask``:
+        uint8 [n_vocab], bit 0 = always suppressed, bit 1 = suppressed at the first sampled position."""
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32) for t in token_lists]), dtype=np.int32)
+        off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
+        rules = WhisperDecodeRules(int(eot), int(timestamp_begin), -1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index), 0)
+        vm = np.ascontiguousarray(vocab_mask, dtype=np.uint8)
+        nxt = np.zeros(len(token_lists), dtype=np.int32)
+        self._check(self._lib.pce_whisper_decode_step(self._ctx, toks.ctypes.data, off.ctypes.data, int(sample_begin), C.byref(rules),
+                                                      vm.ctypes.data, nxt.ctypes.data))
+        return nxt
 
     # ---------------------------------------------------------------- probabilistic YIN (viewers)
     def pyin_run(self, plan, tables):

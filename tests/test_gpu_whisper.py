@@ -146,3 +146,64 @@ def test_median_filter_network_equals_generic_sort(engine, clips, monkeypatch):
         enc = engine.whisper_encode_fetch(i)
         cost, _, _ = WO.find_alignment(toks[i], enc, Wd, tdims, num_frames[i], 3, medfilt_width=5)
         assert np.linalg.norm(got5[i]["cost"] - cost) / np.linalg.norm(cost) <= 3e-2
+
+
+def _greedy_setup(engine):
+    from tests.test_whisper_hf_crosscheck import _greedy_gold
+    g, rules = _greedy_gold()
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=77), WW.greedy_test_decoder_weights(tdims, seed=79)
+    use = [synth.synth_clip(int(ci), seconds=4.0) for ci in g["clips"]]
+    engine.upload(use, 16000)
+    engine.logmel_run(80)
+    engine.whisper_load(edims, WW.pack(We, edims))
+    engine.whisper_encode_run()
+    engine.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+    return g, rules, tdims, Wd, use
+
+
+def test_decode_step_decisions_match_the_restatement(engine):
+    """Free-running decoding, step by step on the golden prefixes (the transformers-driven sequences of
+    tests/golden/whisper_greedy_tiny.npz): the GPU step must pick the golden next token wherever the fp32 restatement's
+    filtered logits leave a margin of 0.05 between the best two (bf16 operands), and never break a timestamp rule."""
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    g, rules, tdims, Wd, use = _greedy_setup(engine)
+    mask = DEC.vocab_mask(tdims["n_vocab"], rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    gold = [g[f"tokens_{int(ci)}"].tolist() for ci in g["clips"]]
+    begin = len(g["initial"])
+    encs = [engine.whisper_encode_fetch(i) for i in range(len(use))]
+    n_checked = n_same = 0
+    for L in list(range(begin, begin + 14)) + [begin + 30, begin + 44]:
+        prefixes = [t[:L] for t in gold]
+        nxt = engine.whisper_decode_step(prefixes, begin, rules["eot"], rules["timestamp_begin"], mask, rules["max_initial_timestamp_index"])
+        for i, p in enumerate(prefixes):
+            logits = WO.find_alignment(p, encs[i], Wd, tdims, 2, 0, want_internal=True)["logits"][-1]
+            f = WO.apply_decoding_rules(logits, p, begin, rules)
+            assert np.isfinite(f[int(nxt[i])]), (L, i, int(nxt[i]))               # never a suppressed / rule-breaking token
+            top = np.sort(f[np.isfinite(f)])[::-1]
+            n_checked += 1
+            if len(top) < 2 or top[0] - top[1] > 0.05:
+                assert int(nxt[i]) == int(np.argmax(f)) == gold[i][L], (L, i)
+                n_same += 1
+    assert n_same >= 0.8 * n_checked
+
+
+def test_greedy_decoding_runs_free_and_obeys_the_rules(engine):
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    g, rules, tdims, Wd, use = _greedy_setup(engine)
+    out = DEC.greedy_decode(engine, tdims["n_vocab"], g["initial"].tolist(), rules, sample_len=40)
+    tsb, eot = rules["timestamp_begin"], rules["eot"]
+    for seq in out:
+        new = seq[len(g["initial"]):]
+        assert 1 <= len(new) <= 40 and new[0] >= tsb and new[0] <= tsb + rules["max_initial_timestamp_index"]
+        assert not (set(new) & set(rules["suppress_tokens"])) and rules["no_timestamps"] not in new
+        stamps = [t for t in new if t >= tsb]
+        assert all(b >= a for a, b in zip(stamps, stamps[1:]))                     # timestamps never decrease
+        for a, b, c in zip(new, new[1:], new[2:]):
+            if a >= tsb and b >= tsb:
+                assert c < tsb                                                    # after a pair: text (or end of text)
+        assert eot not in new[:-1]
+    # the first tokens agree with the transformers-driven golden sequences (margins are comfortable there)
+    gold = [g[f"tokens_{int(ci)}"].tolist() for ci in g["clips"]]
+    assert all(o[:len(g["initial"]) + 3] == w[:len(g["initial"]) + 3] for o, w in zip(out, gold))
