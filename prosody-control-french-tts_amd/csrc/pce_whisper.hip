@@ -790,6 +790,32 @@ __global__ void k_gather_last(const float *__restrict__ resid, const int *__rest
     out[i] = resid[((int64_t)clip * T_pad + t_len[clip] - 1) * d + col];
 }
 
+// self-attention cache maintenance.  k_cache_k: K rows of a prefix run, [clip * T_pad + t][2d] (second half) -> cache
+// [clip][T_cap][d]; k_append_kv: the new position of an incremental step, compact [clip][3d] (q | k | v) -> K row and V^T column.
+__global__ void k_cache_k(const bf16 *__restrict__ qk, int T_pad, const int *__restrict__ t_len, int d, int T_cap, int n, bf16 *__restrict__ ck)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * T_pad * d) return;
+    const int col = (int)(i % d); const int64_t r = i / d; const int t = (int)(r % T_pad), clip = (int)(r / T_pad);
+    if (t < t_len[clip]) ck[((int64_t)clip * T_cap + t) * d + col] = qk[r * 2 * d + d + col];
+}
+__global__ void k_append_kv(const bf16 *__restrict__ qkv, int pos, int d, int T_cap, int sp, int n, bf16 *__restrict__ ck, bf16 *__restrict__ cvt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * d) return;
+    const int clip = (int)(i / d), col = (int)(i - (int64_t)clip * d);
+    ck[((int64_t)clip * T_cap + pos) * d + col] = qkv[(int64_t)clip * 3 * d + d + col];
+    cvt[((int64_t)clip * d + col) * sp + pos] = qkv[(int64_t)clip * 3 * d + 2 * d + col];
+}
+__global__ void k_embed_one(const int *__restrict__ tok, const float *__restrict__ tok_emb, const float *__restrict__ pos_emb, int pos, int d, int n,
+                            float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * d) return;
+    const int clip = (int)(i / d), col = (int)(i - (int64_t)clip * d);
+    out[i] = tok_emb[(int64_t)tok[clip] * d + col] + pos_emb[(int64_t)pos * d + col];
+}
+
 // openai-whisper decoding.py at temperature 0, one workgroup per sequence: SuppressBlank, SuppressTokens,
 // ApplyTimestampRules on the logits of the last position, then the GreedyDecoder's arg-max (first maximum) and its
 // "once end-of-text, always end-of-text" rule.  vmask: bit 0 = always suppressed (suppress list, no_timestamps),
@@ -1086,6 +1112,10 @@ struct WhisperState {
     // free-running decoding: tied output projection in bf16 (rows padded to 128), cross K / V of every layer, last-position buffers
     DevBuf g_emb_bf16, g_xk, g_xvt, g_last, g_lastln, g_logits, g_mask, g_next;
     int g_xkv_clips = -1;            // clips the cross K / V cache was computed for (-1: stale)
+    // self-attention K / V of the sequences decoded so far: K rows [layer][clip][T_cap][d], V^T [layer][clip][d][512]
+    DevBuf g_sk, g_svt, g_c_resid, g_c_ln, g_c_qkv, g_c_attn, g_c_q, g_c_hidden, g_c_tab;
+    std::vector<int> g_cache_tok;     // host copy of the cached prefixes [clip][T_cap]
+    int g_cache_len = -1, g_cache_n = -1;
     struct DLayer { size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, lnx_w, lnx_b, xq_w, xq_b, xkv_w, xkv_b, xout_w, xout_b,
                     ln2_w, ln2_b, m1_w, m1_b, m2_w, m2_b; };
     std::vector<DLayer> dlayers;
@@ -1222,6 +1252,7 @@ void pce_whisper_free(pce_ctx *c)
                       &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
                       &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
+                      &w->g_sk, &w->g_svt, &w->g_c_resid, &w->g_c_ln, &w->g_c_qkv, &w->g_c_attn, &w->g_c_q, &w->g_c_hidden, &w->g_c_tab,
                       &w->g_emb_bf16, &w->g_xk, &w->g_xvt, &w->g_last, &w->g_lastln, &w->g_logits, &w->g_mask, &w->g_next,
                       &w->bert.w_bf16, &w->bert.w_f32, &w->bert.word, &w->bert.pos, &w->bert.type0, &w->bert.tab, &w->bert.tokens, &w->bert.resid,
                       &w->bert.ln, &w->bert.qk, &w->bert.vt, &w->bert.attn, &w->bert.hidden, &w->bert.logits};
@@ -1426,7 +1457,7 @@ int pce_whisper_encode_run(pce_ctx *c)
     hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + w->lnp_w,
                        Wf + w->lnp_b, M, d, w->final_out.as<float>());
     PCE_HIP(c, hipGetLastError());
-    w->n_clips_enc = n; w->g_xkv_clips = -1;
+    w->n_clips_enc = n; w->g_xkv_clips = -1; w->g_cache_len = -1;
     return PCE_OK;
 }
 
@@ -1515,7 +1546,7 @@ int pce_whisper_decoder_load(pce_ctx *c, const pce_whisper_text_dims *dims, cons
     }
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     tmp.release();
-    w->dec_loaded = true; w->g_xkv_clips = -1;
+    w->dec_loaded = true; w->g_xkv_clips = -1; w->g_cache_len = -1;
     return PCE_OK;
 }
 
@@ -1740,8 +1771,6 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     PCE_HIP(c, w->d_attn.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
     PCE_HIP(c, w->d_q.reserve(sizeof(bf16) * (size_t)Mt * d + 4096));
     PCE_HIP(c, w->d_hidden.reserve(sizeof(bf16) * (size_t)Mt * 4 * d + 4096));
-    const size_t dvt_elems = (size_t)n * (size_t)d * SPD + 64;
-    PCE_HIP(c, w->d_vt.reserve(sizeof(bf16) * dvt_elems));
     PCE_HIP(c, w->g_last.reserve(sizeof(float) * (size_t)n * d));
     PCE_HIP(c, w->g_lastln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
     PCE_HIP(c, w->g_logits.reserve(sizeof(float) * (size_t)n * (size_t)Vp));
@@ -1771,8 +1800,74 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
         }
         w->g_xkv_clips = n;
     }
+    // ---- self-attention K / V cache [layer][clip][T_cap] (rows) / [layer][clip][d][512] (transposed)
+    const int T_cap = w->tdims.n_text_ctx;
+    const size_t sk_l = (size_t)n * T_cap * d, svt_l = (size_t)n * (size_t)d * SPD;
+    if (w->g_cache_n != n || !w->g_sk.p) {
+        PCE_HIP(c, w->g_sk.reserve(sizeof(bf16) * sk_l * (size_t)L + 4096));
+        PCE_HIP(c, w->g_svt.reserve(sizeof(bf16) * svt_l * (size_t)L + 4096));
+        PCE_HIP(c, hipMemsetAsync(w->g_sk.p, 0, sizeof(bf16) * sk_l * (size_t)L, c->stream));
+        PCE_HIP(c, hipMemsetAsync(w->g_svt.p, 0, sizeof(bf16) * svt_l * (size_t)L, c->stream));
+        w->g_cache_n = n; w->g_cache_len = -1; w->g_cache_tok.assign((size_t)n * T_cap, 0);
+    }
+    bool uniform = true;
+    for (int i = 1; i < n; i++) uniform = uniform && t_len[(size_t)i] == t_len[0];
+    const int Lc = t_len[0];
+    bool incremental = uniform && w->g_cache_len == Lc - 1 && Lc >= 2 && !getenv("PCE_DECODE_NO_CACHE");
+    for (int i = 0; incremental && i < n; i++)
+        incremental = memcmp(&w->g_cache_tok[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)(Lc - 1)) == 0;
+    const bf16 *last_ln = nullptr;                                // [n][d] bf16: the final LayerNorm of the last position
+    if (incremental) {
+        // ---- one new position per sequence: every GEMM has M = clips rows, the attention one query per (clip, head)
+        const int pos = Lc - 1;
+        std::vector<int> ct((size_t)7 * n);                     // new token | q_row0 | q_len | k_row0 | k_len | a_row0 | a_len
+        for (int i = 0; i < n; i++) {
+            ct[(size_t)i] = tokens[token_offsets[i] + pos]; ct[(size_t)n + i] = i; ct[(size_t)2 * n + i] = 1; ct[(size_t)3 * n + i] = i * T_cap;
+            ct[(size_t)4 * n + i] = Lc; ct[(size_t)5 * n + i] = i * W_CTX; ct[(size_t)6 * n + i] = W_CTX;
+        }
+        PCE_HIP(c, w->g_c_tab.reserve(sizeof(int) * ct.size()));
+        PCE_HIP(c, w->g_c_resid.reserve(sizeof(float) * (size_t)n * d));
+        PCE_HIP(c, w->g_c_ln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+        PCE_HIP(c, w->g_c_qkv.reserve(sizeof(bf16) * (size_t)(n + 128) * 3 * d + 4096));
+        PCE_HIP(c, w->g_c_attn.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+        PCE_HIP(c, w->g_c_q.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+        PCE_HIP(c, w->g_c_hidden.reserve(sizeof(bf16) * (size_t)(n + 128) * 4 * d + 4096));
+        PCE_HIP(c, hipMemcpyAsync(w->g_c_tab.p, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipStreamSynchronize(c->stream));
+        const int *CT = w->g_c_tab.as<int>(), *Q0 = CT + n, *QL = CT + 2 * n, *K0 = CT + 3 * n, *KL = CT + 4 * n, *X0 = CT + 5 * n, *XL = CT + 6 * n;
+        hipLaunchKernelGGL(k_embed_one, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, CT, w->d_tok_emb.as<float>(),
+                           w->d_pos_emb.as<float>(), pos, d, n, w->g_c_resid.as<float>());
+        auto cattn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp, const int *k0, const int *kl) {
+            AttnArgs a{};
+            a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
+            a.q_row0 = Q0; a.q_len = QL; a.k_row0 = k0; a.k_len = kl; a.out = w->g_c_attn.as<bf16>(); a.out_ld = d; a.causal = 0;
+            hipLaunchKernelGGL(k_attention, dim3(1u, (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+        };
+        auto cln = [&](size_t w_off, size_t b_off) {
+            hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w_off, Wf + b_off,
+                               (int64_t)n, d, w->g_c_ln.as<bf16>());
+        };
+        for (int l = 0; l < L; l++) {
+            const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
+            cln(ly.ln1_w, ly.ln1_b);
+            launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, n, 3 * d, d, Wf + ly.qkv_b, w->g_c_qkv.as<bf16>(), 3 * d, 0, 1);
+            hipLaunchKernelGGL(k_append_kv, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, w->g_c_qkv.as<bf16>(), pos, d, T_cap, SPD, n,
+                               w->g_sk.as<bf16>() + sk_l * (size_t)l, w->g_svt.as<bf16>() + svt_l * (size_t)l);
+            cattn(w->g_c_qkv.as<bf16>(), 3 * d, w->g_sk.as<bf16>() + sk_l * (size_t)l, d, w->g_svt.as<bf16>() + svt_l * (size_t)l, (int64_t)d * SPD, SPD, K0, KL);
+            launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.out_w, n, d, d, Wf + ly.out_b, w->g_c_resid.as<float>(), d, 0, 1);
+            cln(ly.lnx_w, ly.lnx_b);
+            launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.xq_w, n, d, d, Wf + ly.xq_b, w->g_c_q.as<bf16>(), d, 0, 1);
+            cattn(w->g_c_q.as<bf16>(), d, w->g_xk.as<bf16>() + xk_l * (size_t)l, d, w->g_xvt.as<bf16>() + xvt_l * (size_t)l, (int64_t)d * AT_SP, AT_SP, X0, XL);
+            launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.xout_w, n, d, d, Wf + ly.xout_b, w->g_c_resid.as<float>(), d, 0, 1);
+            cln(ly.ln2_w, ly.ln2_b);
+            launch_gemm<EPI_GELU_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.m1_w, n, 4 * d, d, Wf + ly.m1_b, w->g_c_hidden.as<bf16>(), 4 * d, 0, 1);
+            launch_gemm<EPI_RESID_F32>(c, w->g_c_hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, n, d, 4 * d, Wf + ly.m2_b, w->g_c_resid.as<float>(), d, 0, 1);
+        }
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w->dln_w, Wf + w->dln_b,
+                           (int64_t)n, d, w->g_lastln.as<bf16>());
+        last_ln = w->g_lastln.as<bf16>();
+    } else {
     PCE_HIP(c, hipMemsetAsync(w->d_attn.p, 0, sizeof(bf16) * (size_t)Mt * d + 4096, c->stream));      // pad rows: no stale bits (see pce_whisper_align_run)
-    PCE_HIP(c, hipMemsetAsync(w->d_vt.p, 0, sizeof(bf16) * dvt_elems, c->stream));
     hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)div_up(Mt * d, 256)), dim3(256), 0, c->stream, w->d_tokens.as<int>(),
                        w->d_tok_emb.as<float>(), w->d_pos_emb.as<float>(), T_pad, w->tdims.n_text_ctx, d, Mt, w->d_resid.as<float>());
     auto attn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp,
@@ -1789,9 +1884,12 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     for (int l = 0; l < L; l++) {
         const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
         ln(ly.ln1_w, ly.ln1_b);
+        bf16 *svt = w->g_svt.as<bf16>() + svt_l * (size_t)l;       // the prefix run fills the cache: V^T straight from the epilogue, K rows copied
         launch_gemm<EPI_QKV>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)Mt, 3 * d, d, Wf + ly.qkv_b, w->d_qk.as<bf16>(), 2 * d, 0, 1,
-                             reinterpret_cast<const float *>(w->d_vt.as<bf16>()), T_pad, 2 * d, SPD);
-        attn(w->d_qk.as<bf16>(), 2 * d, w->d_qk.as<bf16>() + d, 2 * d, w->d_vt.as<bf16>(), (int64_t)d * SPD, SPD, T0, TL, 1);
+                             reinterpret_cast<const float *>(svt), T_pad, 2 * d, SPD);
+        hipLaunchKernelGGL(k_cache_k, dim3((unsigned)div_up(Mt * d, 256)), dim3(256), 0, c->stream, w->d_qk.as<bf16>(), T_pad, TL, d, T_cap, n,
+                           w->g_sk.as<bf16>() + sk_l * (size_t)l);
+        attn(w->d_qk.as<bf16>(), 2 * d, w->d_qk.as<bf16>() + d, 2 * d, svt, (int64_t)d * SPD, SPD, T0, TL, 1);
         launch_gemm<EPI_RESID_F32>(c, w->d_attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)Mt, d, d, Wf + ly.out_b, w->d_resid.as<float>(), d, 0, 1);
         ln(ly.lnx_w, ly.lnx_b);
         launch_gemm<EPI_BF16>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.xq_w, (int)Mt, d, d, Wf + ly.xq_b, w->d_q.as<bf16>(), d, 0, 1);
@@ -1806,8 +1904,15 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
                        w->g_last.as<float>());
     hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_last.as<float>(), Wf + w->dln_w, Wf + w->dln_b,
                        (int64_t)n, d, w->g_lastln.as<bf16>());
+    last_ln = w->g_lastln.as<bf16>();
+    }
+    // the cache now holds every position of these prefixes (when they all have one length)
+    if (uniform) {
+        for (int i = 0; i < n; i++) memcpy(&w->g_cache_tok[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)Lc);
+        w->g_cache_len = Lc;
+    } else w->g_cache_len = -1;
     PCE_HIP(c, hipMemsetAsync(w->g_logits.p, 0, sizeof(float) * (size_t)n * (size_t)Vp, c->stream));
-    launch_gemm<EPI_RESID_F32>(c, w->g_lastln.as<bf16>(), d, 0, w->g_emb_bf16.as<bf16>(), n, (int)Vp, d, nullptr, w->g_logits.as<float>(), Vp, 0, 1);
+    launch_gemm<EPI_RESID_F32>(c, last_ln, d, 0, w->g_emb_bf16.as<bf16>(), n, (int)Vp, d, nullptr, w->g_logits.as<float>(), Vp, 0, 1);
     DecRules R{rules->eot, rules->timestamp_begin, V, (int)Vp, sample_begin, rules->max_initial_timestamp_index};
     hipLaunchKernelGGL(k_decode_rules, dim3((unsigned)n), dim3(256), 0, c->stream, w->g_logits.as<float>(), w->d_tokens.as<int>(), TL, T_pad,
                        w->g_mask.as<unsigned char>(), R, w->g_next.as<int>());

@@ -207,3 +207,16 @@ def test_greedy_decoding_runs_free_and_obeys_the_rules(engine):
     # the first tokens agree with the transformers-driven golden sequences (margins are comfortable there)
     gold = [g[f"tokens_{int(ci)}"].tolist() for ci in g["clips"]]
     assert all(o[:len(g["initial"]) + 3] == w[:len(g["initial"]) + 3] for o, w in zip(out, gold))
+
+
+def test_cached_and_uncached_decoding_agree(engine, monkeypatch):
+    """The per-step K / V cache (one new position per step) against re-running the decoder over the whole prefix
+    (PCE_DECODE_NO_CACHE=1): same tokens, except where bf16 rounding decides a near tie (then the sequences part)."""
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    g, rules, tdims, Wd, use = _greedy_setup(engine)
+    cached = DEC.greedy_decode(engine, tdims["n_vocab"], g["initial"].tolist(), rules, sample_len=30)
+    monkeypatch.setenv("PCE_DECODE_NO_CACHE", "1")
+    plain = DEC.greedy_decode(engine, tdims["n_vocab"], g["initial"].tolist(), rules, sample_len=30)
+    monkeypatch.delenv("PCE_DECODE_NO_CACHE")
+    agree = [next((k for k, (a, b) in enumerate(zip(x, y)) if a != b), min(len(x), len(y))) for x, y in zip(cached, plain)]
+    assert min(agree) >= len(g["initial"]) + 6 and sum(a == min(len(x), len(y)) for a, x, y in zip(agree, cached, plain)) >= 2
