@@ -261,7 +261,8 @@ int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32
  * pce_whisper_encode_run and kept. */
 typedef struct pce_whisper_decode_rules { int32_t eot, timestamp_begin, max_initial_timestamp_index /* < 0: none */, reserved; } pce_whisper_decode_rules;
 int pce_whisper_decode_step(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets /* [clips + 1] */, int32_t sample_begin,
-                            const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens /* [clips] */);
+                            const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens /* [clips] */,
+                            float *next_logprobs /* [clips] or NULL: log-probability of the choice under the filtered distribution (sum_logprobs) */);
 
 /* ---- R8: dynamic time warping (alignment indices) ------------------------
  * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on

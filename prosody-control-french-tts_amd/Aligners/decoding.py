@@ -29,8 +29,10 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
     seqs = [list(initial_tokens) for _ in range(n)]
     begin = len(initial_tokens)
     mask = vocab_mask(n_vocab, rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    sum_logprobs = np.zeros(n, dtype=np.float64)
     for _ in range(sample_len):
         nxt = engine.whisper_decode_step(seqs, begin, rules["eot"], rules["timestamp_begin"], mask, rules.get("max_initial_timestamp_index"))
+        sum_logprobs += engine.last_decode_logprobs                 # (0 for sequences that had already ended: GreedyDecoder.update)
         for s, t in zip(seqs, nxt):
             s.append(int(t))
         if all(s[-1] == rules["eot"] for s in seqs):
@@ -40,4 +42,5 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
         new = s[begin:]
         cut = new.index(rules["eot"]) + 1 if rules["eot"] in new else len(new)
         out.append(s[:begin + cut])
+    greedy_decode.last_sum_logprobs = sum_logprobs                  # avg_logprob of transcribe = sum / (tokens + 1)
     return out

@@ -822,7 +822,8 @@ __global__ void k_embed_one(const int *__restrict__ tok, const float *__restrict
 // bit 1 = suppressed at the first sampled position (blank, end of text).
 struct DecRules { int eot, ts_begin, n_vocab, ld, sample_begin, max_initial_ts; };
 __global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits, const int *__restrict__ tokens, const int *__restrict__ t_len,
-                                                     int T_pad, const unsigned char *__restrict__ vmask, DecRules R, int *__restrict__ next)
+                                                     int T_pad, const unsigned char *__restrict__ vmask, DecRules R, int *__restrict__ next,
+                                                     float *__restrict__ next_logprob)
 {
     __shared__ float r_f[2][4]; __shared__ int r_i[4]; __shared__ float s_bcast[2]; __shared__ int s_flags[4];
     const int clip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -895,6 +896,24 @@ __global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits
         for (int u = 1; u < 4; u++) if (r_f[0][u] > best || (r_f[0][u] == best && r_i[u] < bi)) { best = r_f[0][u]; bi = r_i[u]; }
         if (bi == 0x7fffffff) bi = only_ts ? R.ts_begin : 0;       // every candidate is -inf: torch.argmax returns the first index
         next[clip] = done ? R.eot : bi;
+        s_bcast[1] = best;
+    }
+    __syncthreads();
+    // log-probability of the choice under the filtered distribution (GreedyDecoder.update adds it to sum_logprobs unless
+    // the sequence had already ended): log_softmax over what is left after the filters
+    {
+        const float top = s_bcast[1];
+        float se2 = 0.f;
+        if (top > NEG)
+            for (int v = (only_ts ? R.ts_begin : 0) + tid; v < R.n_vocab; v += 256) se2 += __expf(x[v] - top);
+        for (int o = 32; o > 0; o >>= 1) se2 += __shfl_xor(se2, o, 64);
+        __syncthreads();
+        if (lane == 0) r_f[1][wv] = se2;
+        __syncthreads();
+        if (tid == 0) {
+            const float tot = (r_f[1][0] + r_f[1][1]) + (r_f[1][2] + r_f[1][3]);
+            next_logprob[clip] = (done || !(top > NEG)) ? 0.f : -__logf(tot);     // x[best] - logsumexp = -log(sum exp(x - best))
+        }
     }
 }
 
@@ -1733,7 +1752,8 @@ int pce_whisper_align_shape(pce_ctx *c, int32_t clip, int32_t *n_rows, int32_t *
 // self-attention is the next refinement).
 // ---------------------------------------------------------------------------
 extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, int32_t sample_begin,
-                                       const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens)
+                                       const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens,
+                                       float *next_logprobs)
 {
     if (!c || !tokens || !token_offsets || !rules || !vocab_mask || !next_tokens) return PCE_E_INVALID;
     WhisperState *w = ws_of(c);
@@ -1775,7 +1795,7 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     PCE_HIP(c, w->g_lastln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
     PCE_HIP(c, w->g_logits.reserve(sizeof(float) * (size_t)n * (size_t)Vp));
     PCE_HIP(c, w->g_mask.reserve((size_t)V + 64));
-    PCE_HIP(c, w->g_next.reserve(sizeof(int) * (size_t)n));
+    PCE_HIP(c, w->g_next.reserve((sizeof(int) + sizeof(float)) * (size_t)n));
     PCE_HIP(c, hipMemcpyAsync(w->d_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipMemcpyAsync(w->d_tokens.p, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipMemcpyAsync(w->g_mask.p, vocab_mask, (size_t)V, hipMemcpyHostToDevice, c->stream));
@@ -1915,9 +1935,10 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     launch_gemm<EPI_RESID_F32>(c, last_ln, d, 0, w->g_emb_bf16.as<bf16>(), n, (int)Vp, d, nullptr, w->g_logits.as<float>(), Vp, 0, 1);
     DecRules R{rules->eot, rules->timestamp_begin, V, (int)Vp, sample_begin, rules->max_initial_timestamp_index};
     hipLaunchKernelGGL(k_decode_rules, dim3((unsigned)n), dim3(256), 0, c->stream, w->g_logits.as<float>(), w->d_tokens.as<int>(), TL, T_pad,
-                       w->g_mask.as<unsigned char>(), R, w->g_next.as<int>());
+                       w->g_mask.as<unsigned char>(), R, w->g_next.as<int>(), reinterpret_cast<float *>(w->g_next.as<int>() + n));
     PCE_HIP(c, hipGetLastError());
     PCE_HIP(c, hipMemcpyAsync(next_tokens, w->g_next.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (next_logprobs) PCE_HIP(c, hipMemcpyAsync(next_logprobs, w->g_next.as<int>() + n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     return PCE_OK;
 }

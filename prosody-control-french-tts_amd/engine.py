@@ -147,7 +147,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_decoder_load.argtypes = [vp, C.POINTER(WhisperTextDims), vp, i64]
     lib.pce_whisper_align_run.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_float]
     lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
-    lib.pce_whisper_decode_step.argtypes = [vp, vp, vp, i32, C.POINTER(WhisperDecodeRules), vp, vp]
+    lib.pce_whisper_decode_step.argtypes = [vp, vp, vp, i32, C.POINTER(WhisperDecodeRules), vp, vp, vp]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
@@ -458,9 +458,10 @@ class ProsodyEngine:
         off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
         rules = WhisperDecodeRules(int(eot), int(timestamp_begin), -1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index), 0)
         vm = np.ascontiguousarray(vocab_mask, dtype=np.uint8)
-        nxt = np.zeros(len(token_lists), dtype=np.int32)
+        nxt = np.zeros(len(token_lists), dtype=np.int32); lp = np.zeros(len(token_lists), dtype=np.float32)
         self._check(self._lib.pce_whisper_decode_step(self._ctx, toks.ctypes.data, off.ctypes.data, int(sample_begin), C.byref(rules),
-                                                      vm.ctypes.data, nxt.ctypes.data))
+                                                      vm.ctypes.data, nxt.ctypes.data, lp.ctypes.data))
+        self.last_decode_logprobs = lp
         return nxt
 
     # ---------------------------------------------------------------- probabilistic YIN (viewers)

@@ -181,6 +181,8 @@ def test_decode_step_decisions_match_the_restatement(engine):
             logits = WO.find_alignment(p, encs[i], Wd, tdims, 2, 0, want_internal=True)["logits"][-1]
             f = WO.apply_decoding_rules(logits, p, begin, rules)
             assert np.isfinite(f[int(nxt[i])]), (L, i, int(nxt[i]))               # never a suppressed / rule-breaking token
+            lp = f - (np.max(f) + np.log(np.sum(np.exp(f[np.isfinite(f)] - np.max(f)))))       # log_softmax of the filtered logits
+            assert abs(float(engine.last_decode_logprobs[i]) - float(lp[int(nxt[i])])) <= 0.05, (L, i)
             top = np.sort(f[np.isfinite(f)])[::-1]
             n_checked += 1
             if len(top) < 2 or top[0] - top[1] > 0.05:
