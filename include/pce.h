@@ -220,6 +220,10 @@ typedef struct pce_whisper_dims {
     int32_t n_layer;
 } pce_whisper_dims;
 int pce_logmel_run(pce_ctx *ctx, int32_t n_mels);
+/* window variant (whisper.transcribe slices the log-mel of the WHOLE recording, followed by 30 s of zeros, at its seek
+ * position): frames start_frames[clip] .. +2999 of that spectrogram, samples beyond 30 s included, the max - 8 clamp from
+ * the maximum over the whole recording.  start_frames[clip] * 160 must not exceed the clip length. */
+int pce_logmel_run_at(pce_ctx *ctx, int32_t n_mels, const int64_t *start_frames /* [clips] */);
 int pce_logmel_fetch(pce_ctx *ctx, int32_t clip, float *out /* [n_mels][3000] */);
 int pce_whisper_load(pce_ctx *ctx, const pce_whisper_dims *dims, const float *weights, int64_t n_floats);
 int pce_whisper_encode_run(pce_ctx *ctx);

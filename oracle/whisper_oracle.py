@@ -57,6 +57,25 @@ def log_mel(pcm_i16: np.ndarray, n_mels=80) -> np.ndarray:
     return log_spec[:, :N_FRAMES].numpy()
 
 
+def log_mel_window(pcm_i16: np.ndarray, start_frame: int, n_mels=80) -> np.ndarray:
+    """The mel segment ``whisper.transcribe`` hands to the model at seek position ``start_frame``:
+    ``log_mel_spectrogram(audio, padding=N_SAMPLES)`` of the WHOLE recording (reflect-padded STFT, drop the last frame,
+    clamp at the global maximum - 8, (x + 4) / 4), then ``mel[:, seek : seek + N_FRAMES]`` (padded to 3000 frames)."""
+    audio = torch.from_numpy(np.asarray(pcm_i16, dtype=np.float32) / 32768.0)
+    audio = F.pad(audio, (0, N_SAMPLES))
+    window = torch.hann_window(N_FFT)
+    stft = torch.stft(audio, N_FFT, HOP, window=window, return_complex=True)
+    mag = stft[..., :-1].abs() ** 2
+    mel = torch.from_numpy(mel_filters(n_mels)) @ mag
+    log_spec = torch.clamp(mel, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    log_spec = (log_spec + 4.0) / 4.0
+    seg = log_spec[:, start_frame:start_frame + N_FRAMES]
+    if seg.shape[1] < N_FRAMES:
+        seg = F.pad(seg, (0, N_FRAMES - seg.shape[1]))
+    return seg.numpy().astype(np.float32)
+
+
 def sinusoids(length, channels, max_timescale=10000):
     inc = np.log(max_timescale) / (channels // 2 - 1)
     inv = torch.exp(-inc * torch.arange(channels // 2))

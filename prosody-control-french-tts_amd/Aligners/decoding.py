@@ -44,3 +44,75 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
         out.append(s[:begin + cut])
     greedy_decode.last_sum_logprobs = sum_logprobs                  # avg_logprob of transcribe = sum / (tokens + 1)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Windows of a long recording: the seek logic of whisper.transcribe (openai-whisper transcribe.py, restated; the
+# package is absent: parity unpinned, hand-made cases in tests/test_decoding_host.py)
+# ---------------------------------------------------------------------------------------------------------------
+N_FRAMES = 3000                 # mel frames per 30 s window
+INPUT_STRIDE = 2                # mel frames per audio token
+TIME_PRECISION = 0.02           # seconds per timestamp step
+
+
+def segments_and_seek(tokens, timestamp_begin: int, seek: int, segment_size: int = N_FRAMES):
+    """One decoded window (sampled tokens, end-of-text removed) -> (segments, new_seek).
+
+    As whisper.transcribe: consecutive timestamp pairs cut the window into segments; when the window ends on a single
+    timestamp the whole window is consumed, otherwise the seek moves to the last closed timestamp; a window without
+    consecutive timestamps is one segment and is consumed whole.  segments: dicts with start / end (seconds, absolute)
+    and the token slice."""
+    tokens = [int(t) for t in tokens]
+    time_offset = seek * 0.01
+    is_ts = [t >= timestamp_begin for t in tokens]
+    single_timestamp_ending = is_ts[-2:] == [False, True]
+    consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+    segments = []
+    if consecutive:
+        slices = list(consecutive)
+        if single_timestamp_ending:
+            slices.append(len(tokens))
+        last = 0
+        for cur in slices:
+            sl = tokens[last:cur]
+            segments.append({"start": time_offset + (sl[0] - timestamp_begin) * TIME_PRECISION,
+                             "end": time_offset + (sl[-1] - timestamp_begin) * TIME_PRECISION, "tokens": sl})
+            last = cur
+        if single_timestamp_ending:
+            seek += segment_size
+        else:
+            seek += (tokens[last - 1] - timestamp_begin) * INPUT_STRIDE
+    else:
+        duration = segment_size * 0.01
+        stamps = [t for t in tokens if t >= timestamp_begin]
+        if stamps and stamps[-1] != timestamp_begin:
+            duration = (stamps[-1] - timestamp_begin) * TIME_PRECISION
+        segments.append({"start": time_offset, "end": time_offset + duration, "tokens": tokens})
+        seek += segment_size
+    return segments, seek
+
+
+def transcribe_tokens(engine, n_mels: int, n_vocab: int, initial_tokens, rules: dict, sample_len: int, max_windows: int = 64):
+    """Greedy transcription of every clip of the engine's resident 16 kHz batch, window by window:
+    log-mel window at each clip's seek position (``logmel_run_at``), encoder, ``greedy_decode``, ``segments_and_seek``.
+    -> per clip the list of segments (token ids; absolute times).  The encoder and decoder weights must be loaded."""
+    lens = [int(n) for n in engine.clip_lengths]
+    content = [n // 160 for n in lens]
+    seeks = [0] * len(lens)
+    out = [[] for _ in lens]
+    for _ in range(max_windows):
+        active = [i for i in range(len(lens)) if seeks[i] < content[i]]
+        if not active:
+            break
+        engine.logmel_run_at(n_mels, [min(seeks[i], content[i]) for i in range(len(lens))])
+        engine.whisper_encode_run()
+        seqs = greedy_decode(engine, n_vocab, initial_tokens, rules, sample_len)
+        for i in active:
+            new = [t for t in seqs[i][len(initial_tokens):] if t != rules["eot"]]
+            seg_size = min(N_FRAMES, content[i] - seeks[i])
+            if not new:
+                seeks[i] += seg_size
+                continue
+            segs, seeks[i] = segments_and_seek(new, rules["timestamp_begin"], seeks[i], seg_size)
+            out[i].extend(segs)
+    return out

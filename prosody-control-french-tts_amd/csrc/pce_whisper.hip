@@ -63,9 +63,13 @@ __device__ __forceinline__ float f32_from_key(unsigned int k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// frame0 == nullptr: the window is frames 0..2999 of the clip trimmed to 30 s (pad_or_trim + log_mel_spectrogram).
+// frame0 != nullptr: whisper.transcribe's slicing of the log-mel of the WHOLE clip followed by 30 s of zeros: the window is
+// frames frame0[clip] .. +2999, samples beyond 30 s exist, and (scan != 0) a first launch reduces the maximum over every
+// frame that overlaps audio (the frames of pure padding are at the -10 floor) without writing anything.
 __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict__ pcm, const int64_t *__restrict__ clip_off, int n_mels,
                                                       MelTables T, float *__restrict__ logspec /* [clip][n_mels][3000] */,
-                                                      unsigned int *__restrict__ clip_max)
+                                                      unsigned int *__restrict__ clip_max, const int64_t *__restrict__ frame0, int scan)
 {
     __shared__ float xs[4][W_NFFT];
     __shared__ float2 ys[4][25 * 16];
@@ -77,12 +81,16 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
     for (int i = tid; i < 400; i += 256) s_w400[i] = T.w400[i];
     __syncthreads();
     const int clip = blockIdx.y;
-    const int64_t base = clip_off[clip], len = min<int64_t>(clip_off[clip + 1] - base, (int64_t)W_SAMPLES);
+    const int64_t base = clip_off[clip], full = clip_off[clip + 1] - base;
+    const int64_t len = frame0 ? full : min<int64_t>(full, (int64_t)W_SAMPLES);
+    const int64_t f_begin = (frame0 && !scan) ? frame0[clip] : 0;
+    const int64_t n_fr = scan ? (full + W_NFFT / 2) / W_HOP + 1 : W_FRAMES;       // scan: every frame that can see a sample
     float vmax = -1e30f;
-    for (int frame = blockIdx.x * 4 + wv; frame < W_FRAMES; frame += gridDim.x * 4) {
+    for (int64_t fl = blockIdx.x * 4 + wv; fl < n_fr; fl += gridDim.x * 4) {
+        const int64_t frame = f_begin + fl;
         // windowed frame, centre = frame*160, reflect padding at the start, zeros past the audio
         for (int n = lane; n < W_NFFT; n += 64) {
-            int64_t i = (int64_t)frame * W_HOP - W_NFFT / 2 + n;
+            int64_t i = frame * W_HOP - W_NFFT / 2 + n;
             if (i < 0) i = -i;
             const float v = (i < len) ? (float)pcm[base + i] * (1.0f / 32768.0f) : 0.0f;
             xs[wv][n] = v * T.window[n];
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
             float acc = 0.f;
             for (int i = 0; i < cnt; i++) acc = fmaf(w[i], pw[wv][lo + i], acc);
             const float lg = log10f(fmaxf(acc, 1e-10f));
-            logspec[((int64_t)clip * n_mels + b) * W_FRAMES + frame] = lg;
+            if (!scan) logspec[((int64_t)clip * n_mels + b) * W_FRAMES + fl] = lg;
             vmax = fmaxf(vmax, lg);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -1120,7 +1128,7 @@ void mel_filterbank(int n_mels, std::vector<float> &dense)
 struct WhisperState {
     pce_whisper_dims dims{};
     bool loaded = false;
-    DevBuf tables, logspec, clipmax, mel_tm, w_bf16, w_f32, pos;
+    DevBuf tables, logspec, clipmax, mel_tm, mel_start, w_bf16, w_f32, pos;
     DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab;
     size_t vt_elems_zeroed = 0;
     // text decoder
@@ -1267,7 +1275,7 @@ void pce_whisper_free(pce_ctx *c)
 {
     if (!c->whisper) return;
     WhisperState *w = static_cast<WhisperState *>(c->whisper);
-    DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
+    DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->mel_start, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
                       &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
                       &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
@@ -1282,7 +1290,14 @@ void pce_whisper_free(pce_ctx *c)
 
 extern "C" {
 
-int pce_logmel_run(pce_ctx *c, int32_t n_mels)
+static int logmel_run_impl(pce_ctx *c, int32_t n_mels, const int64_t *start_frames);
+int pce_logmel_run(pce_ctx *c, int32_t n_mels) { return logmel_run_impl(c, n_mels, nullptr); }
+int pce_logmel_run_at(pce_ctx *c, int32_t n_mels, const int64_t *start_frames)
+{
+    if (!start_frames) return PCE_E_INVALID;
+    return logmel_run_impl(c, n_mels, start_frames);
+}
+static int logmel_run_impl(pce_ctx *c, int32_t n_mels, const int64_t *start_frames)
 {
     if (!c) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
@@ -1299,10 +1314,28 @@ int pce_logmel_run(pce_ctx *c, int32_t n_mels)
     PCE_HIP(c, w->mel_tm.reserve(sizeof(bf16) * tm_elems));
     PCE_HIP(c, hipMemsetAsync(w->clipmax.p, 0, sizeof(unsigned int) * (size_t)n, c->stream));
     PCE_HIP(c, hipMemsetAsync(w->mel_tm.p, 0, sizeof(bf16) * tm_elems, c->stream));
+    const int64_t *d_start = nullptr;
+    if (start_frames) {
+        int64_t longest = 0;
+        for (int32_t i = 0; i < n; i++) {
+            const int64_t len = c->clip_off[(size_t)i + 1] - c->clip_off[(size_t)i];
+            if (start_frames[i] < 0 || start_frames[i] * W_HOP > len) return pce_fail(c, PCE_E_INVALID, "clip %d: window start %lld frames is past the audio", i, (long long)start_frames[i]);
+            longest = std::max(longest, len);
+        }
+        PCE_HIP(c, w->mel_start.reserve(sizeof(int64_t) * (size_t)(n > 0 ? n : 1)));
+        PCE_HIP(c, hipMemcpyAsync(w->mel_start.p, start_frames, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        PCE_HIP(c, hipStreamSynchronize(c->stream));
+        d_start = w->mel_start.as<int64_t>();
+        if (n > 0) {       // the clamp of log_mel_spectrogram uses the maximum over the whole recording
+            const int64_t scan_frames = (longest + W_NFFT / 2) / W_HOP + 1;
+            hipLaunchKernelGGL(k_logmel_frames, dim3((unsigned)std::min<int64_t>(div_up(scan_frames, 4 * 5), 4096), (unsigned)n), dim3(256), 0, c->stream, c->d_pcm,
+                               c->d_clip_off.as<int64_t>(), (int)n_mels, w->mt, w->logspec.as<float>(), w->clipmax.as<unsigned int>(), d_start, 1);
+        }
+    }
     {
         KernelTimer t(c, PCE_K_LOGMEL);
         hipLaunchKernelGGL(k_logmel_frames, dim3(W_FRAMES / 4 / 5, (unsigned)n), dim3(256), 0, c->stream, c->d_pcm,
-                           c->d_clip_off.as<int64_t>(), (int)n_mels, w->mt, w->logspec.as<float>(), w->clipmax.as<unsigned int>());
+                           c->d_clip_off.as<int64_t>(), (int)n_mels, w->mt, w->logspec.as<float>(), w->clipmax.as<unsigned int>(), d_start, 0);
         hipLaunchKernelGGL(k_logmel_norm, dim3(div_up(W_FRAMES, 64), div_up(n_mels, 64), (unsigned)n), dim3(256), 0, c->stream,
                            w->logspec.as<float>(), w->clipmax.as<unsigned int>(), (int)n_mels, w->mel_tm.as<bf16>());
     }

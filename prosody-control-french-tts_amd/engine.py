@@ -101,7 +101,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
            "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step",
-           "pce_logmel_run", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
+           "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
 
@@ -153,6 +153,7 @@ def load_library() -> C.CDLL:
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
     lib.pce_bert_fetch.argtypes = [vp, i32, vp, vp]
     lib.pce_logmel_run.argtypes = [vp, i32]
+    lib.pce_logmel_run_at.argtypes = [vp, i32, vp]
     lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
     lib.pce_whisper_encode_run.argtypes = [vp]
@@ -366,6 +367,13 @@ class ProsodyEngine:
     def logmel_run(self, n_mels: int = 80):
         self._n_mels = int(n_mels)
         self._check(self._lib.pce_logmel_run(self._ctx, int(n_mels)))
+
+    def logmel_run_at(self, n_mels: int, start_frames):
+        """The 30 s window that starts ``start_frames[clip]`` frames (10 ms each) into every clip, as ``whisper.transcribe``
+        slices the log-mel of the whole recording at its seek position."""
+        sf = np.ascontiguousarray(start_frames, dtype=np.int64)
+        self._check(self._lib.pce_logmel_run_at(self._ctx, int(n_mels), sf.ctypes.data))
+        self._n_mels = int(n_mels)
 
     def logmel_fetch(self, clip: int) -> np.ndarray:
         out = np.zeros((self._n_mels, 3000), dtype=np.float32)

@@ -222,3 +222,47 @@ def test_cached_and_uncached_decoding_agree(engine, monkeypatch):
     monkeypatch.delenv("PCE_DECODE_NO_CACHE")
     agree = [next((k for k, (a, b) in enumerate(zip(x, y)) if a != b), min(len(x), len(y))) for x, y in zip(cached, plain)]
     assert min(agree) >= len(g["initial"]) + 6 and sum(a == min(len(x), len(y)) for a, x, y in zip(agree, cached, plain)) >= 2
+
+
+def test_logmel_windows_of_a_long_recording(engine):
+    """Recordings longer than 30 s (segment_ph6 of the demo data runs 37.2 s): the window whisper.transcribe takes at a
+    seek position is a slice of the log-mel of the WHOLE recording, clamped with the global maximum."""
+    rng = np.random.default_rng(12)
+    t = np.arange(16000 * 37) / 16000.0
+    long_clip = np.round(6000 * np.sin(2 * np.pi * (200 + 3 * t) * t) * (np.sin(2 * np.pi * 0.4 * t) > -0.3) + 200 * rng.standard_normal(len(t))).astype(np.int16)
+    long_clip[16000 * 33:] //= 40                                   # a quiet tail: its frames sit below the global clamp
+    short = synth.synth_clip(2, seconds=4.0)
+    clips = [long_clip, short, long_clip]
+    engine.upload(clips, 16000)
+    starts = [1500, 0, 3000]
+    engine.logmel_run_at(80, starts)
+    for i, (c, s0) in enumerate(zip(clips, starts)):
+        got = engine.logmel_fetch(i)
+        want = WO.log_mel_window(c, s0, 80)
+        assert got.shape == want.shape == (80, 3000)
+        assert np.max(np.abs(got - want)) <= 2e-3, (i, float(np.max(np.abs(got - want))))
+    engine.logmel_run_at(80, [0, 0, len(long_clip) // 160])           # a window that starts at the very end: all padding
+    assert np.max(np.abs(engine.logmel_fetch(2) - WO.log_mel_window(long_clip, len(long_clip) // 160, 80))) <= 2e-3
+    assert np.max(np.abs(engine.logmel_fetch(1) - WO.log_mel(short, 80))) <= 2e-3        # <= 30 s at start 0: the plain front end
+    from prosody_control_french_tts_amd import PceError
+    with pytest.raises(PceError):
+        engine.logmel_run_at(80, [0, 500, 0])                         # past the end of the 4 s clip
+
+
+def test_windowed_transcription_loop_terminates_and_advances(engine):
+    """Aligners.decoding.transcribe_tokens on a 37 s and a 4 s recording (tiny random-init model): every window is decoded
+    at its seek position, the seek only moves forward, segments carry absolute times within the recording."""
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    g, rules, tdims, Wd, _ = _greedy_setup(engine)
+    rng = np.random.default_rng(3)
+    t = np.arange(16000 * 37) / 16000.0
+    long_clip = np.round(5000 * np.sin(2 * np.pi * (180 + 2 * t) * t) + 300 * rng.standard_normal(len(t))).astype(np.int16)
+    clips = [long_clip, synth.synth_clip(4, seconds=4.0)]
+    engine.upload(clips, 16000)
+    segs = DEC.transcribe_tokens(engine, 80, tdims["n_vocab"], g["initial"].tolist(), rules, sample_len=30)
+    assert len(segs) == 2 and len(segs[0]) >= 2 and len(segs[1]) >= 1
+    for i, c in enumerate(clips):
+        starts = [s["start"] for s in segs[i]]
+        assert all(b >= a for a, b in zip(starts, starts[1:])) and starts[0] >= 0.0
+        assert all(s["end"] >= s["start"] for s in segs[i]) and segs[i][-1]["start"] <= len(c) / 16000.0
+    assert segs[0][-1]["end"] > 30.0                                   # the long recording was decoded past the first window
