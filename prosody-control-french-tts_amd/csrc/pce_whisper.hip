@@ -1797,6 +1797,7 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     const int n = w->n_clips_enc, d = w->tdims.n_state, H = w->tdims.n_head, L = w->tdims.n_layer, V = w->tdims.n_vocab, SPD = 512;
     if (rules->eot < 0 || rules->eot >= V || rules->timestamp_begin <= rules->eot || rules->timestamp_begin > V || sample_begin < 1)
         return pce_fail(c, PCE_E_INVALID, "decoding rules: need 0 <= eot < timestamp_begin <= n_vocab, sample_begin >= 1");
+    if (n == 0) return PCE_OK;
     int T_max = 0;
     std::vector<int> t_len((size_t)n);
     for (int i = 0; i < n; i++) {
