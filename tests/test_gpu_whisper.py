@@ -266,3 +266,18 @@ def test_windowed_transcription_loop_terminates_and_advances(engine):
         assert all(b >= a for a, b in zip(starts, starts[1:])) and starts[0] >= 0.0
         assert all(s["end"] >= s["start"] for s in segs[i]) and segs[i][-1]["start"] <= len(c) / 16000.0
     assert segs[0][-1]["end"] > 30.0                                   # the long recording was decoded past the first window
+
+
+def test_alignment_reads_the_cross_kv_a_decoding_step_left(engine):
+    """pce_whisper_align_run projects the encoder output to cross-attention K / V itself unless a decoding step has already
+    done so for this encoded batch: the two routes must give the same cost matrices bit for bit."""
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    g, rules, tdims, Wd, use = _greedy_setup(engine)
+    toks = [g[f"tokens_{int(ci)}"].tolist()[:20] for ci in g["clips"]]
+    frames = [len(c) // 160 for c in use]
+    alone = engine.whisper_align(toks, frames, 3, want_cost=True)
+    mask = DEC.vocab_mask(tdims["n_vocab"], rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    engine.whisper_decode_step([t[:5] for t in toks], 3, rules["eot"], rules["timestamp_begin"], mask, rules["max_initial_timestamp_index"])
+    after = engine.whisper_align(toks, frames, 3, want_cost=True)
+    for a, b in zip(alone, after):
+        assert a["cost"].tobytes() == b["cost"].tobytes() and np.array_equal(a["time_indices"], b["time_indices"])
