@@ -15,7 +15,10 @@
 namespace {
 
 constexpr int EN_THREADS = 256;
-constexpr int EN_ITERS = 8;
+#ifndef PCE_EN_ITERS
+#define PCE_EN_ITERS 8
+#endif
+constexpr int EN_ITERS = PCE_EN_ITERS;
 constexpr int64_t EN_CHUNK = (int64_t)EN_THREADS * 8 * EN_ITERS;   // 16384 samples = 32 KiB
 
 struct EnWork { int64_t g0, g1; int32_t slice; int32_t pad; };
