@@ -1,9 +1,11 @@
-// pce_whisper.hip -- log-mel spectrogram and Whisper audio encoder (R8) on gfx950.
+// pce_whisper.hip -- the transformer work of the alignment step (R8) on gfx950: log-mel spectrogram, Whisper audio encoder,
+// text decoder (teacher-forced forced alignment with cross-attention DTW; free-running greedy decoding with a K / V
+// cache and openai-whisper's logit filters), and the break-prediction BERT forward, which shares the same kernels.
 //
-// Replaces the device work that whisper_timestamped.transcribe
-// (Code/Aligners/use_whisper_timestamped.py:139,150-163) performs before decoding, as
-// openai-whisper==20240930 defines it (third-party, restated from its published
-// architecture; parity unpinned, checked against a torch fp32 restatement in oracle/):
+// Replaces the device work of whisper_timestamped.transcribe
+// (Code/Aligners/use_whisper_timestamped.py:139,150-163), as openai-whisper==20240930 defines it (third-party,
+// restated from its published architecture; the torch fp32 restatement in oracle/ is pinned against the installed
+// transformers port of the same network: tests/test_whisper_hf_crosscheck.py):
 //   log_mel_spectrogram: Hann(400) STFT hop 160 (centre, reflect padding), |.|^2, 80 Slaney
 //     mel bands, log10(max(.,1e-10)), max(., max-8), (.+4)/4, 30 s window = 3000 frames
 //   AudioEncoder: conv1d(80->d,k3,p1)+GELU, conv1d(d->d,k3,s2,p1)+GELU, + sinusoid positions,
