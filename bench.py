@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips", type=int, default=256, help="clips timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--whisper-model", choices=["tiny", "base", "small", "medium"], default="small",
+                    help="architecture of the c3 workload (BASELINE.json names small; the reference's config.yaml:15 default is medium)")
     ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
                     help="c2 (default, BASELINE.json configs[1]): F0+energy+LUFS+STFT; c3: c2 + log-mel + Whisper-small encoder")
     args = ap.parse_args()
@@ -185,9 +187,9 @@ def main():
     wdims = None
     if args.workload == "c3":
         from prosody_control_french_tts_amd import whisper_weights as WW
-        wdims = WW.DIMS["small"]
+        wdims = WW.DIMS[args.whisper_model]
         eng.whisper_load(wdims, WW.pack(WW.synthetic_weights(wdims), wdims))       # random-init weights of the architecture
-        tdims = WW.TEXT_DIMS["small"]
+        tdims = WW.TEXT_DIMS[args.whisper_model]
         eng.whisper_decoder_load(tdims, WW.pack_decoder(WW.synthetic_decoder_weights(tdims), tdims))
         trng = np.random.default_rng(5)
         sot_len = 3                                    # <|sot|><|fr|><|transcribe|> ... <|eot|>: synthetic ids of a 10 s utterance's length
@@ -278,7 +280,7 @@ def main():
             flop = args.clips * (2.0 * 3000 * d * 240 + 2.0 * 1500 * d * 3 * d
                                  + L * (2.0 * 1500 * d * 3 * d + 4.0 * 1500 * 1500 * d + 2.0 * 1500 * d * d + 16.0 * 1500 * d * d))
             stages += [("log-mel (R8)", ["k_logmel"], pcm + 80 * 3000 * 4.0 * args.clips, None),
-                       ("whisper-small encoder (R8)", ["whisper_encoder"], None, flop)]
+                       (f"whisper-{args.whisper_model} encoder (R8)", ["whisper_encoder"], None, flop)]
             # (the forced-alignment leg -- decoder over 24-48 tokens per clip, alignment heads, DTW -- is timed as `whisper_align` in `kernels`)
         # k_energy runs three times per step (gate, LUFS peak, pitch peak): split its time over the users
         rows = []
@@ -325,7 +327,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, "
                                    "energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256; "
-                                   + ("+ log-mel + Whisper-small encoder + teacher-forced decoder / cross-attention DTW alignment (synthetic weights and token ids, bf16 MFMA)" if wdims else "Whisper-encoder alignment (C3) not included: --workload c3"),
+                                   + (f"+ log-mel + Whisper-{args.whisper_model} encoder + teacher-forced decoder / cross-attention DTW alignment (synthetic weights and token ids, bf16 MFMA)" if wdims else "Whisper-encoder alignment (C3) not included: --workload c3"),
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip"},
             "roofline": roofline, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
