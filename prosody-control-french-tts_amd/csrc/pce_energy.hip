@@ -57,10 +57,31 @@ __global__ __launch_bounds__(EN_THREADS) void k_energy(const int16_t *__restrict
         const int64_t pos = p0 + (int64_t)it * EN_THREADS * 8;
         v[it] = pos < w.g1 ? *reinterpret_cast<const int4 *>(pcm + pos) : make_int4(0, 0, 0, 0);
     }
+    // Loads that lie wholly inside the slice (all but the first and last of a chunk) take the packed route: two samples
+    // per instruction on v_dot2_i32_i16 (x0^2 + x1^2, x0 + x1, the sum of the two wrapped squares), v_pk_mul_lo_u16 (the
+    // int16-wrapped squares themselves) and v_pk_max_i16 / v_pk_min_i16 (extrema); the per-sample route handles edges.
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 ones = {1, 1};
+    s2 pmax = {-32768, -32768}, pmin = {32767, 32767};
+    bool any_packed = false;
 #pragma unroll
     for (int it = 0; it < EN_ITERS; it++) {
         const int64_t pos = p0 + (int64_t)it * EN_THREADS * 8;
         const int words[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        if (pos >= w.g0 && pos + 8 <= w.g1) {
+            any_packed = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const s2 xv = __builtin_bit_cast(s2, words[k]);
+                s_sq += (unsigned long long)(unsigned int)__builtin_amdgcn_sdot2(xv, xv, 0, false);      // <= 2^31: exact as unsigned
+                s_sum = __builtin_amdgcn_sdot2(xv, ones, s_sum, false);
+                s_wrap = __builtin_amdgcn_sdot2(xv * xv, ones, s_wrap, false);                           // (int16)(x^2) per half, summed
+                pmax = __builtin_elementwise_max(pmax, xv); pmin = __builtin_elementwise_min(pmin, xv);
+                const s2 ab = __builtin_elementwise_max(xv, (s2){0, 0} - xv);                             // |x| as int16: |-32768| wraps to -32768
+                n_loud += ((int)ab.x > loud_thr) + ((int)ab.y > loud_thr);
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int lo = (int)(short)(words[k] & 0xFFFF), hi = words[k] >> 16;
@@ -77,6 +98,11 @@ __global__ __launch_bounds__(EN_THREADS) void k_energy(const int16_t *__restrict
             m_hi = max(m_hi, max(ok0 ? x0 + 32769 : 0, ok1 ? x1 + 32769 : 0));
             m_lo = max(m_lo, max(ok0 ? 32768 - x0 : 0, ok1 ? 32768 - x1 : 0));
         }
+    }
+    if (any_packed) {
+        const int hi = max((int)pmax.x, (int)pmax.y), lo = min((int)pmin.x, (int)pmin.y);
+        peak = max(peak, max(hi < 0 ? -hi : hi, lo < 0 ? -lo : lo));
+        m_hi = max(m_hi, hi + 32769); m_lo = max(m_lo, 32768 - lo);
     }
     __shared__ unsigned long long l_sq[EN_THREADS / 64];
     __shared__ long long l_wrap[EN_THREADS / 64];
