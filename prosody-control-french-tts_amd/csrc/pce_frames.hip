@@ -36,6 +36,15 @@ __global__ __launch_bounds__(FR_THREADS) void k_frame_energy(const int16_t *__re
             auto consume = [&](const int4 v, int r) {            // r = index of the load's first sample within the frame (-7 ..)
                 const int words[4] = {v.x, v.y, v.z, v.w};
                 const bool inside = r >= 0 && r + 8 <= nfr;        // interior loads skip the per-sample range tests
+                if (inside && !requantize) {                       // ... and square two samples per instruction (v_dot2_i32_i16)
+                    typedef short s2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const s2 xv = __builtin_bit_cast(s2, words[q]);
+                        s += (unsigned long long)(unsigned int)__builtin_amdgcn_sdot2(xv, xv, 0, false);
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     int x0 = (int)(short)(words[q] & 0xFFFF), x1 = words[q] >> 16;
