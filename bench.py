@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the prosody hot path on MI355X.
+"""bench.py -- throughput of the prosody + alignment hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 10 s 16 kHz
-mono clips, resident in HBM as int16 before the timed region.  One step = one pass of the
+Default workload (BASELINE.json configs[2], "C3", the configuration the metric is quoted on): per GPU a batch of
+256 synthetic 10 s 16 kHz mono clips, resident in HBM as int16 before the timed region.  One step = one pass of the
 hot path over the batch:
-    k_energy (gate/peak/RMS integers)  +  BS.1770 LUFS  +  Praat-AC F0 (150-600 Hz) with path
-    finding and voiced median  +  STFT-dB 1024/256,
-followed by the fetch of the per-utterance statistics (a few KB) and, for N > 1, the single
-all-gather of those statistics (RCCL).  The 329 MB STFT-dB result stays in HBM.
+    log-mel + Whisper-small audio encoder + teacher-forced text decoder / cross-attention DTW alignment (bf16 MFMA)
+    + k_energy (gate / peak / RMS integers) + BS.1770 LUFS + Praat-AC F0 (150-600 Hz) with path finding and voiced
+    median + STFT-dB 1024/256,
+followed by the fetch of the per-utterance statistics (a few KB) and, for N > 1, the single all-gather of those
+statistics (RCCL).  `--workload c2` (configs[1]) leaves the Whisper leg out.
 
     python bench.py --gpus N --steps K --warmup W
-prints ONE JSON line on rank 0.  `value` = audio seconds processed by all ranks / wall time.
+prints ONE JSON line (rank 0).  `value` = audio seconds processed by all ranks / wall time.  With --gpus N > 1 and no
+WORLD_SIZE in the environment this process starts the N ranks itself (it never touches the GPU: the ranks are fresh
+child processes); under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
+`--gpus 8 --clips 1250` is configs[3] (C4: 10 000 clips over 8 GPUs).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,22 +32,24 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (never the 2:1-sparsity figure)
+VALU_F64_PEAK_TFLOPS = 78.6     # fp64 vector peak (79 TF/s)
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+COMPOSITE = ("whisper_encoder", "whisper_align", "bert_forward", "whisper_decode_step")   # brackets around several launches
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 for the
-    gfx950 wide-read under-count + WRITE_SIZE, KB -> B; tools/pmc_traffic.py), committed under profiles/."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+def load_pmc_traffic(workload):
+    """HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 for the gfx950 wide-read
+    under-count + WRITE_SIZE, KB -> B; tools/pmc_traffic.py), committed under profiles/."""
     try:
-        with open(path) as f:
-            t = json.load(f)["bytes_per_launch"]
-        if "k_stft_raw" in t and "k_stft_db" not in t:      # the dB pass is timed as `k_stft_db` whichever kernel implements it
-            t["k_stft_db"] = t["k_stft_raw"]
-        return t
+        with open(os.path.join(PROFILE_DIR, f"pmc_traffic_{workload}.json")) as f:
+            return json.load(f)["bytes_per_launch"]
     except Exception:
         return None
 
 
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle: test infrastructure, used here only as the thing timed BESIDE the engine)
+# --------------------------------------------------------------------------------------------------------------
 def _cpu_one(args):
     c, rate = args
     from oracle import oracle as O
@@ -78,30 +86,17 @@ def _cpu_one_reference_shaped(args):
     return n
 
 
-def load_pmc_valu(kernel):
-    """Mean SQ_INSTS_VALU per launch of `kernel` from the committed rocprofv3 --pmc pass of this command."""
-    import csv
-    import re
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_sq_counter_collection.csv")
-    try:
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if r["Counter_Name"] == "SQ_INSTS_VALU" and re.search(r"\b" + kernel + r"\b", r["Kernel_Name"])]
-        return sum(vals) / len(vals) if vals else None
-    except Exception:
-        return None
-
-
-def cpu_baseline(clips, rate, budget_clips):
-    """The CPU oracle ("port": C double-precision restatement) on a bounded sample: one thread (`value`, the
-    contract's figure) and, as `all_cores`, utterance-parallel over the host's cores the way the reference runs
-    one process per voice (config.yaml:58)."""
+def cpu_prosody_baseline(clips, rate, budget_clips):
+    """C2 leg of the CPU port: one thread (`value`), utterance-parallel worker processes (`all_cores`, the way the
+    reference runs one process per voice, config.yaml:58) and the reference-shaped call pattern (paths in, the file
+    decoded again by every measurement)."""
     sample = clips[:budget_clips]
     t0 = time.perf_counter()
     for c in sample:
         _cpu_one((c, rate))
     dt = time.perf_counter() - t0
     secs = sum(len(c) for c in sample) / rate
-    out = {"value": secs / dt, "unit": "audio-seconds/sec", "cores": 1, "kind": "port",
+    out = {"value": secs / dt, "unit": "audio-seconds/sec", "cores": 1, "kind": "port", "seconds": dt, "clips": len(sample),
            "sample": f"{len(sample)} of the same synthetic 10 s clips, oracle/pce_oracle.c + numpy, {dt:.1f} s of CPU time"}
     try:
         # worker PROCESSES (fork): called before this process touches the GPU, see main()
@@ -116,7 +111,6 @@ def cpu_baseline(clips, rate, budget_clips):
     except Exception as e:                                         # the single-thread figure is the contract's
         out["all_cores"] = {"error": str(e)}
     try:
-        # reference-shaped: paths in, seven decodes per file (SURVEY.md section 8d iii), one thread, 32 clips
         import tempfile
         import wave
         sub = sample[:32]
@@ -138,44 +132,148 @@ def cpu_baseline(clips, rate, budget_clips):
     return out
 
 
+def cpu_whisper_baseline(clips, rate, model, W_enc, W_dec, dims, tdims, align_tokens, sot_len, budget_s=15.0, max_clips=4):
+    """C3 leg of the CPU port: log-mel, the audio encoder and the forced alignment of the same clips through the
+    float32 restatement (oracle/whisper_oracle.py, torch CPU kernels on torch's intra-op threads), bounded by time."""
+    import torch
+    from oracle import whisper_oracle as WO
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    done = 0
+    for i, c in enumerate(clips[:max_clips]):
+        mel = WO.log_mel(c, dims["n_mels"])
+        enc = WO.encoder_forward(mel, W_enc, dims)
+        WO.find_alignment(align_tokens[i], enc, W_dec, tdims, num_frames=len(c) // 160, sot_len=sot_len)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"clips": done, "seconds": dt, "seconds_per_clip": dt / done, "threads": threads,
+            "what": f"oracle/whisper_oracle.py log_mel + encoder_forward + find_alignment, Whisper-{model} size, float32"}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a rendezvous in the environment
+# --------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start N fresh rank processes of this script (one per GPU) and relay rank 0's JSON line.  This parent never
+    imports torch.cuda nor the engine: no process that has initialised the GPU is ever re-executed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=600 if rc == 0 else 20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 6 for c3, 20 for c2)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 2 for c3, 3 for c2)")
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-clips", type=int, default=256, help="clips timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=256, help="clips timed on the CPU oracle's prosody leg (0 = no cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--whisper-model", choices=["tiny", "base", "small", "medium"], default="small",
                     help="architecture of the c3 workload (BASELINE.json names small; the reference's config.yaml:15 default is medium)")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
-                    help="c2 (default, BASELINE.json configs[1]): F0+energy+LUFS+STFT; c3: c2 + log-mel + Whisper-small encoder")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c3",
+                    help="c3 (default, BASELINE.json configs[2]): prosody + log-mel + Whisper encoder + forced alignment; "
+                         "c2 (configs[1]): F0 + energy + LUFS + STFT only")
+    ap.add_argument("--streamed-steps", type=int, default=4, help="extra steps with the batch uploaded from pinned host memory "
+                    "(double buffered) for `streamed_value`; 0 = skip")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the rank launcher and the exchange (gloo, no engine, no throughput)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 6 if args.workload == "c3" else 20
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "c3" else 3
 
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"]); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    run_rank(args, world, rank, local_rank)
+
+
+def run_rank(args, world, rank, local_rank):
     import torch
     import torch.distributed as dist
-    import prosody_control_french_tts_amd as pkg
     from prosody_control_french_tts_amd import shard, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rate = 16000
     n_samples = int(round(args.seconds * rate))
+    counts = [args.clips] * world
+
+    if args.selftest_launcher:
+        # launcher + exchange only, on CPU: every rank contributes a record block that encodes its rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        rec = np.full((args.clips, 7), float(rank)); rec[:, 1] = np.arange(args.clips)
+        got = shard.allgather_records(rec, counts)
+        ok = got.shape == (args.clips * world, 7) and all((got[r * args.clips:(r + 1) * args.clips, 0] == r).all() for r in range(world))
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test (no throughput)", "value": None, "n_gpus": world, "exchange_ok": bool(ok),
+                              "records": int(got.shape[0]), "data": "host-only"}))
+        if not ok:
+            sys.exit(1)
+        return
+
+    import prosody_control_french_tts_amd as pkg
     # synthetic data of the workload's shape; rank r owns clips [r*clips, (r+1)*clips) (weak scaling)
     clips = synth.synth_batch(args.clips, args.seconds, rate, first=rank * args.clips)
+    wdims = tdims = None
+    if args.workload == "c3":
+        from prosody_control_french_tts_amd import whisper_weights as WW
+        wdims, tdims = WW.DIMS[args.whisper_model], WW.TEXT_DIMS[args.whisper_model]
+        W_enc, W_dec = WW.synthetic_weights(wdims), WW.synthetic_decoder_weights(tdims)      # random-init weights of the architecture
+        trng = np.random.default_rng(5 + rank)
+        sot_len = 3                                    # <|sot|><|fr|><|transcribe|> ... <|eot|>: synthetic ids of a 10 s utterance's length
+        align_tokens = [trng.integers(0, tdims["n_vocab"], size=int(trng.integers(24, 48))).tolist() for _ in range(args.clips)]
+        align_frames = [n_samples // 160] * args.clips
     # CPU baseline first: its all-cores leg forks worker processes, which must happen before this process
-    # initialises the GPU
-    # (rank 0 of a single-GPU run only: the multi-GPU lines carry "cpu_baseline": null)
-    cpu = cpu_baseline(clips, rate, args.cpu_clips) if (world == 1 and rank == 0 and args.cpu_clips > 0) else None
-    if args.gpus > 1 or world > 1:
+    # initialises the GPU (rank 0 of a single-GPU run only: the multi-GPU lines carry "cpu_baseline": null)
+    cpu = None
+    if world == 1 and rank == 0 and args.cpu_clips > 0:
+        cpu = cpu_prosody_baseline(clips, rate, args.cpu_clips)
+        if wdims:
+            wh = cpu_whisper_baseline(clips, rate, args.whisper_model, W_enc, W_dec, wdims, tdims, align_tokens, sot_len)
+            per_clip = cpu["seconds"] / cpu["clips"] + wh["seconds_per_clip"]
+            cpu["prosody_leg"] = {"value": cpu["value"], "cores": 1, "sample": cpu["sample"]}
+            cpu["whisper_leg"] = wh
+            cpu["value"] = args.seconds / per_clip
+            cpu["cores"] = wh["threads"]
+            cpu["sample"] = (f"C3 per-clip time = prosody leg ({cpu['clips']} clips, C oracle, one thread) + Whisper leg ({wh['clips']} clips, "
+                             f"{wh['seconds']:.1f} s, torch CPU float32 on {wh['threads']} threads); {cpu['seconds'] + wh['seconds']:.1f} s of CPU work")
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(local_rank)
     eng = pkg.ProsodyEngine(local_rank)
     eng.upload(clips, rate)                      # inputs resident in HBM before the timed region
     sl = eng.whole_clip_slices()
@@ -183,23 +281,14 @@ def main():
     off, _ = eng.pitch_plan(sl, params)
     n_pitch_frames = int(off[1] - off[0])
     n_stft_frames = 1 + n_samples // 256
-
-    wdims = None
-    if args.workload == "c3":
-        from prosody_control_french_tts_amd import whisper_weights as WW
-        wdims = WW.DIMS[args.whisper_model]
-        eng.whisper_load(wdims, WW.pack(WW.synthetic_weights(wdims), wdims))       # random-init weights of the architecture
-        tdims = WW.TEXT_DIMS[args.whisper_model]
-        eng.whisper_decoder_load(tdims, WW.pack_decoder(WW.synthetic_decoder_weights(tdims), tdims))
-        trng = np.random.default_rng(5)
-        sot_len = 3                                    # <|sot|><|fr|><|transcribe|> ... <|eot|>: synthetic ids of a 10 s utterance's length
-        align_tokens = [trng.integers(0, tdims["n_vocab"], size=int(trng.integers(24, 48))).tolist() for _ in range(args.clips)]
-        align_frames = [n_samples // 160] * args.clips
+    if wdims:
+        eng.whisper_load(wdims, WW.pack(W_enc, wdims))
+        eng.whisper_decoder_load(tdims, WW.pack_decoder(W_dec, tdims))
 
     # One step = one pass of the hot path over the batch: launch() enqueues every kernel of the pass and the
     # asynchronous copy of the per-utterance statistics; finish() waits for that copy only, builds the 7-stat
-    # record and all-gathers it.  Consecutive steps are software-pipelined (step i+1 is enqueued before step i's
-    # record is read), so the device does not idle while the host unpacks: two statistic slots are in flight.
+    # record and all-gathers it (ONE collective).  Consecutive steps are software-pipelined (step i+1 is enqueued
+    # before step i's record is read), so the device does not idle while the host unpacks: two statistic slots.
     def launch(slot):
         if wdims:
             eng.logmel_run(wdims["n_mels"])
@@ -217,11 +306,13 @@ def main():
         # per-utterance record: [median F0, LUFS, rms, peak, silence ratio, duration, n_voiced]
         rec = np.stack([pi["median_f0"], lu, np.sqrt(en["sum_sq"] / np.maximum(en["n"], 1)), en["peak_abs"].astype(np.float64),
                         1.0 - en["n_loud"] / np.maximum(en["n"], 1), en["n"] / float(rate), pi["n_voiced"].astype(np.float64)], axis=1)
-        return shard.allgather_records(rec)
+        return shard.allgather_records(rec, counts)
 
-    def run_steps(k):
+    def run_steps(k, before_launch=None):
         rec = None
         for i in range(k):
+            if before_launch:
+                before_launch(i)
             launch(i & 1)
             if i > 0:
                 rec = finish((i - 1) & 1)
@@ -254,13 +345,56 @@ def main():
     audio_seconds = args.clips * args.seconds * world * args.steps
     assert rec.shape == (args.clips * world, 7)
 
+    # H2D-inclusive rate: the batch arrives from pinned host memory every step, double buffered (the copy of batch i+1
+    # runs on a copy stream beside the kernels of batch i; the engine adopts the device buffer without a copy).
+    streamed = None
+    if args.streamed_steps > 0:
+        try:
+            flat = np.concatenate(clips)
+            host = torch.from_numpy(flat).pin_memory()
+            bufs = [torch.empty(flat.size + 64, dtype=torch.int16, device="cuda") for _ in range(3)]
+            offs = np.zeros(len(clips) + 1, dtype=np.int64); np.cumsum([len(c) for c in clips], out=offs[1:])
+            copy_stream = torch.cuda.Stream()
+            ready = [torch.cuda.Event() for _ in range(3)]
+
+            def stage(i):
+                with torch.cuda.stream(copy_stream):
+                    bufs[i % 3][:flat.size].copy_(host, non_blocking=True)
+                    ready[i % 3].record(copy_stream)
+
+            def before(i):
+                # three buffers: the copy of batch i+1 lands in the buffer batch i-2 used, whose statistics have been
+                # collected (finish(i-2) ran), while batch i-1 may still be on the device and batch i is being enqueued
+                if i == 0:
+                    stage(0)
+                ready[i % 3].synchronize()                      # batch i is in HBM
+                eng.bind_device(bufs[i % 3].data_ptr(), offs, rate, keepalive=bufs)
+                if i + 1 < args.streamed_steps:
+                    stage(i + 1)
+            fence()
+            t0 = time.perf_counter()
+            run_steps(args.streamed_steps, before)
+            fence()
+            dts = time.perf_counter() - t0
+            streamed = {"value": args.clips * args.seconds * args.streamed_steps / dts, "ms_per_step": dts / args.streamed_steps * 1e3,
+                        "steps": args.streamed_steps, "h2d_bytes_per_step": int(flat.size * 2),
+                        "what": "per GPU: the int16 batch is copied from pinned host memory every step on a copy stream (three device buffers) "
+                                "beside the previous batch's kernels; host-side planning of the new batch included"}
+        except Exception as e:                                      # never lose the main line over the extra measurement
+            streamed = {"error": repr(e)}
+
     if rank == 0:
         # per-kernel figures (HIP events on the engine's stream around every launch)
         kernels = []
         for name, p in prof.items():
             avg_ms = p["total_ms"] / p["launches"]
-            kernels.append({"kernel": name, "avg_ms": avg_ms, "launches_per_step": p["launches"] / args.steps,
-                            "ms_per_step": p["total_ms"] / args.steps})
+            k = {"kernel": name, "avg_ms": avg_ms, "launches_per_step": p["launches"] / args.steps, "ms_per_step": p["total_ms"] / args.steps}
+            if p.get("flops"):
+                k["flops_per_launch"] = p["flops"] / p["launches"]
+                k["achieved_tflops"] = p["flops"] / (p["total_ms"] * 1e-3) / 1e12
+            if name in COMPOSITE:
+                k["composite"] = True                                # a bracket around several launches, not a kernel
+            kernels.append(k)
         kernels.sort(key=lambda k: -k["ms_per_step"])
         kt = {k["kernel"]: k for k in kernels}
         # stages: a stage's algorithmic bytes are moved ONCE by its kernels together; the
@@ -282,56 +416,65 @@ def main():
             stages += [("log-mel (R8)", ["k_logmel"], pcm + 80 * 3000 * 4.0 * args.clips, None),
                        (f"whisper-{args.whisper_model} encoder (R8)", ["whisper_encoder"], None, flop)]
             # (the forced-alignment leg -- decoder over 24-48 tokens per clip, alignment heads, DTW -- is timed as `whisper_align` in `kernels`)
-        # k_energy runs three times per step (gate, LUFS peak, pitch peak): split its time over the users
+        kernel_stage_bytes = {}
         rows = []
         for name, ks, nbytes, flops in stages:
-            ms = sum(kt[k]["ms_per_step"] for k in ks if k in kt)
-            if name.startswith("energy") and "k_energy" in kt:
-                ms = kt["k_energy"]["avg_ms"]
-            if ms <= 0:
+            present = [k for k in ks if k in kt]
+            if not present:
                 continue
-            dom = max((k for k in ks if k in kt), key=lambda k: kt[k]["ms_per_step"])
+            ms = sum(kt[k]["ms_per_step"] for k in present)
+            for k in present:
+                kernel_stage_bytes[k] = (name, nbytes)
+            dom = max(present, key=lambda k: kt[k]["ms_per_step"])
             if flops is None:
                 ach = nbytes / (ms * 1e-3) / 1e9
-                rows.append({"stage": name, "kernels": ks, "dominant_kernel": dom, "ms_per_step": ms, "bound": "hbm",
+                rows.append({"stage": name, "kernels": present, "dominant_kernel": dom, "ms_per_step": ms, "bound": "hbm",
                              "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
             else:
                 ach = flops / (ms * 1e-3) / 1e12
-                rows.append({"stage": name, "kernels": ks, "dominant_kernel": dom, "ms_per_step": ms, "bound": "mfma",
+                rows.append({"stage": name, "kernels": present, "dominant_kernel": dom, "ms_per_step": ms, "bound": "mfma",
                              "algorithmic_flops": flops, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": ach / MFMA_BF16_PEAK_TFLOPS})
         rows.sort(key=lambda r: -r["ms_per_step"])
-        traffic = load_pmc_traffic()
+        traffic = load_pmc_traffic(args.workload)
+        # roofline of the DOMINANT KERNEL (largest device time per step among single kernels): its algorithmic work per
+        # launch / its own average launch duration (HIP events on the stream it is launched on) / the peak that bounds it
         roofline = None
-        if rows:
-            r0 = rows[0]
-            t0 = traffic.get(r0["dominant_kernel"]) if traffic else None
-            roofline = {"kernel": r0["dominant_kernel"], "stage": r0["stage"], "bound": r0["bound"], "achieved": r0["achieved"],
-                        "peak": r0["peak"], "unit": r0["unit"], "frac": r0["frac"], "traffic": t0,
-                        "note": "dominant stage by device time; `achieved` = the stage's algorithmic bytes (or flops) / the device time "
-                                "of the stage's kernels.  The F0 stage is fp64-VALU bound (about 1e3 flop per algorithmic byte, "
-                                "DESIGN.md section 3): its HBM fraction is small by construction; `stages` lists every stage.  "
-                                "Issue-slot view of the dominant kernel (profiles/r01/pmc_sq_counter_collection.csv): "
-                                "`valu_f64` prices k_pitch_refine's SQ_INSTS_VALU at the measured 4.6 cycles per fp64 wave-instruction "
-                                "against the 1024 SIMDs' issue capacity over the kernel's duration.",
-                        "valu_f64": {"kernel": "k_pitch_refine", "insts_valu_per_launch": load_pmc_valu("k_pitch_refine"), "cycles_per_inst": 4.6,
-                                     "simds": 1024, "clock_ghz": 2.1,
-                                     "issue_frac": ((load_pmc_valu("k_pitch_refine") or 0.0) * 4.6 / (1024 * 2.1e9)) / max(kt["k_pitch_refine"]["avg_ms"] * 1e-3, 1e-9)
-                                     if "k_pitch_refine" in kt else None,
-                                     "source": "SQ_INSTS_VALU from profiles/r01 (separate rocprofv3 --pmc pass of this command)"}}
+        leaf = [k for k in kernels if not k.get("composite")]
+        if leaf:
+            k0 = leaf[0]
+            tr = traffic.get(k0["kernel"]) if traffic else None
+            if k0.get("flops_per_launch"):
+                ach = k0["flops_per_launch"] / (k0["avg_ms"] * 1e-3) / 1e12
+                roofline = {"kernel": k0["kernel"], "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": tr, "avg_launch_ms": k0["avg_ms"],
+                            "launches_per_step": k0["launches_per_step"], "algorithmic_flops_per_launch": k0["flops_per_launch"],
+                            "note": "dominant kernel by device time per step; achieved = 2MNK (mean over this kernel's launches in a step: "
+                                    "conv, QKV / out-proj / fc1 / fc2 shapes) / its mean launch duration; dense bf16 peak 2.5 PFLOP/s at 2.4 GHz"}
+            elif k0["kernel"] in kernel_stage_bytes:
+                sname, nbytes = kernel_stage_bytes[k0["kernel"]]
+                ach = nbytes / (k0["avg_ms"] * 1e-3) / 1e9
+                roofline = {"kernel": k0["kernel"], "stage": sname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": tr, "avg_launch_ms": k0["avg_ms"], "algorithmic_bytes_per_launch": nbytes,
+                            "note": "dominant kernel by device time per step; achieved = the algorithmic bytes of its stage (SURVEY.md 8d: "
+                                    "PCM in + results out, intermediates excluded) / this kernel's own mean launch duration.  The F0 kernels are "
+                                    "fp64-VALU bound (about 1e3 flop per algorithmic byte): their HBM fraction is small by construction"}
         info = eng.device_info()
+        what = ("energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256"
+                + (f" + log-mel + Whisper-{args.whisper_model} encoder + teacher-forced decoder / cross-attention DTW alignment "
+                   "(synthetic weights and token ids, bf16 MFMA)" if wdims else ""))
         print(json.dumps({
-            "metric": "audio-seconds/sec prosody+align throughput, 16 kHz French",
+            "metric": ("audio-seconds/sec prosody+align throughput, 16 kHz French" if wdims
+                       else "audio-seconds/sec prosody throughput (no alignment leg), 16 kHz French"),
             "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, "
-                                   "energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256; "
-                                   + (f"+ log-mel + Whisper-{args.whisper_model} encoder + teacher-forced decoder / cross-attention DTW alignment (synthetic weights and token ids, bf16 MFMA)" if wdims else "Whisper-encoder alignment (C3) not included: --workload c3"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (MFMA legs) + f64 (F0 / LUFS)" if wdims else "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, " + what,
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
-                       "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip"},
+                       "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)"},
             "roofline": roofline, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
-            "device": info["name"], "host_cores": os.cpu_count(),
+            "streamed_value": streamed, "device": info["name"], "host_cores": os.cpu_count(),
         }))
     eng.close()
     if world > 1:

@@ -319,11 +319,17 @@ enum pce_kernel_id {
     PCE_K_LUFS_PASS1, PCE_K_LUFS_SCAN, PCE_K_LUFS_PASS2, PCE_K_LUFS_GATE,
     PCE_K_PITCH_REFINE, PCE_K_PITCH_FRAMES, PCE_K_PITCH_PATH, PCE_K_PITCH_MEDIAN, PCE_K_PITCH_DELTA,
     PCE_K_STFT_MAX, PCE_K_STFT_DB, PCE_K_LOGMEL, PCE_K_WHISPER_ENC, PCE_K_RESAMPLE, PCE_K_DTW, PCE_K_WHISPER_ALIGN, PCE_K_NW, PCE_K_STFT_NORM,
-    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_WHISPER_DECODE, PCE_K_COUNT
+    PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_WHISPER_DECODE,
+    /* the launches inside the composite entries above (whisper_encoder, whisper_align, bert_forward, whisper_decode_step),
+     * each bracketed on its own so that a roofline figure divides one kernel's work by that kernel's own duration */
+    PCE_K_GEMM128, PCE_K_GEMM_WIDE, PCE_K_ATTENTION, PCE_K_LAYERNORM, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);
 int pce_profile_get(pce_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+/* algorithmic work of the bracketed launches of a kernel id since the last reset: floating-point operations
+ * (2 M N K of a GEMM launch, 4 T^2 d of an attention launch; 0 for ids that do not count) */
+int pce_profile_get_work(pce_ctx *ctx, int kernel_id, double *flops);
 const char *pce_kernel_name(int kernel_id);
 
 #ifdef __cplusplus

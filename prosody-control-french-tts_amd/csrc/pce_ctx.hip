@@ -14,7 +14,7 @@ int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-KernelTimer::KernelTimer(pce_ctx *ctx, int kid, hipStream_t on) : c(ctx), id(kid), s(on ? on : ctx->stream)
+KernelTimer::KernelTimer(pce_ctx *ctx, int kid, hipStream_t on, double work_flops) : c(ctx), id(kid), s(on ? on : ctx->stream), flops(work_flops)
 {
     if (!c->prof) return;
     auto take = [&]() -> hipEvent_t {
@@ -30,7 +30,7 @@ KernelTimer::~KernelTimer()
 {
     if (!c->prof || !a || !b) return;
     (void)hipEventRecord(b, s);
-    c->pending.push_back({id, a, b});
+    c->pending.push_back({id, a, b, flops});
 }
 int pce_side_join(pce_ctx *c, int which)
 {
@@ -74,6 +74,7 @@ void pce_profile_collect(pce_ctx *ctx, bool wait)
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ctx->prof_ms[p.id] += ms;
             ctx->prof_n[p.id] += 1;
+            ctx->prof_flops[p.id] += p.flops;
         }
         ctx->ev_pool.push_back(p.a);
         ctx->ev_pool.push_back(p.b);
@@ -116,6 +117,11 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->no_side = getenv("PCE_NO_AUX") != nullptr;
     c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
+    c->dbg_pitch_lds_fft = getenv("PCE_PITCH_LDS_FFT") != nullptr;
+    c->dbg_pitch_tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) : -1;
+    c->dbg_pitch = getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0;
+    c->refine_blocks_per_cu = getenv("PCE_K2_BPC") ? atoi(getenv("PCE_K2_BPC")) : 24;
+    if (c->refine_blocks_per_cu < 1) c->refine_blocks_per_cu = 24;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int si = 0; si < pce_ctx::SIDE_COUNT; si++) {
@@ -310,7 +316,7 @@ int pce_profile_reset(pce_ctx *c)
 {
     if (!c) return PCE_E_INVALID;
     pce_profile_collect(c);
-    for (int i = 0; i < PCE_K_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    for (int i = 0; i < PCE_K_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_flops[i] = 0; }
     return PCE_OK;
 }
 int pce_profile_get(pce_ctx *c, int id, double *ms, int64_t *n)
@@ -321,12 +327,20 @@ int pce_profile_get(pce_ctx *c, int id, double *ms, int64_t *n)
     if (n) *n = c->prof_n[id];
     return PCE_OK;
 }
+int pce_profile_get_work(pce_ctx *c, int id, double *flops)
+{
+    if (!c || id < 0 || id >= PCE_K_COUNT) return PCE_E_INVALID;
+    pce_profile_collect(c);
+    if (flops) *flops = c->prof_flops[id];
+    return PCE_OK;
+}
 const char *pce_kernel_name(int id)
 {
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
-        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step"};
+        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
+        "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

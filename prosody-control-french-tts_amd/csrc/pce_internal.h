@@ -51,6 +51,8 @@ struct pce_ctx {
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; } side[SIDE_COUNT];
     bool no_side = false;                // PCE_NO_AUX at pce_create: everything on `stream`
     bool generic_median = false;         // PCE_ALIGN_GENERIC_MEDIAN at pce_create: the insertion-sort median filter for every width
+    // debugging / tuning knobs, read once at pce_create (never in a launch path)
+    bool dbg_pitch_lds_fft = false; int dbg_pitch_tabs = -1, dbg_pitch = 0, refine_blocks_per_cu = 24;
     bool stft_two_fft = false;           // PCE_STFT_TWO_FFT at pce_create: traffic-minimal STFT-dB (the FFT runs twice)
     std::string err;
     int cu_count = 0;
@@ -126,7 +128,8 @@ struct pce_ctx {
     bool prof = false;
     double prof_ms[PCE_K_COUNT] = {0};
     int64_t prof_n[PCE_K_COUNT] = {0};
-    struct Pending { int id; hipEvent_t a, b; };
+    double prof_flops[PCE_K_COUNT] = {0};
+    struct Pending { int id; hipEvent_t a, b; double flops; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -141,8 +144,8 @@ int pce_fail(pce_ctx *ctx, int code, const char *fmt, ...);
 
 // Kernel-launch bracket for the profiler: records events around the launch when enabled.
 struct KernelTimer {
-    pce_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; hipStream_t s;
-    KernelTimer(pce_ctx *ctx, int kid, hipStream_t on = nullptr);
+    pce_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; hipStream_t s; double flops;
+    KernelTimer(pce_ctx *ctx, int kid, hipStream_t on = nullptr, double work_flops = 0.0);
     ~KernelTimer();
 };
 void pce_profile_collect(pce_ctx *ctx, bool wait = true);

@@ -1415,12 +1415,12 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
             // register-resident transforms where N allows it and r[-bix..bix] fits the exchange region
             // (tables stay in global memory: staging them in LDS per workgroup measured slower than L1 hits)
-            P.mode = getenv("PCE_PITCH_LDS_FFT") ? 0
+            P.mode = c->dbg_pitch_lds_fft ? 0
                      : (nfft == 1024 && P.rr_len <= R_WAVE_F64) ? 1
                      : (nfft == 512 && P.rr_len <= R_WAVE_F64 / 2) ? 2
                      : (nfft == 2048 && P.rr_len <= R3_WAVE_F64) ? 3 : 0;
             P.fpb = P.mode == 2 ? 2 * PI_FPB : PI_FPB;
-            P.tabs = P.mode == 3 ? 0 : getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) != 0 : P.mode == 2;   // MODE 3: 75 KB of exchange images leave no room
+            P.tabs = P.mode == 3 ? 0 : c->dbg_pitch_tabs >= 0 ? c->dbg_pitch_tabs != 0 : P.mode == 2;   // MODE 3: 75 KB of exchange images leave no room
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
             for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
@@ -1549,7 +1549,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                                        c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
                                        c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
                                        c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap,
-                                       getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0, c->pi_blob.as<double>());
+                                       c->dbg_pitch, c->pi_blob.as<double>());
                 };
                 if (P.mode == 1 && P.tabs) launch(k_pitch_frames<4, 1, true>);
                 else if (P.mode == 1) launch(k_pitch_frames<4, 1, false>);
@@ -1563,7 +1563,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             {
                 KernelTimer t(c, PCE_K_PITCH_REFINE);
                 // 3 workgroups per CU are resident (168 VGPRs); 24 per CU measured best (1.30 ms against 1.47 at 3: the lists are uneven)
-                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (getenv("PCE_K2_BPC") ? (unsigned)atoi(getenv("PCE_K2_BPC")) : 24u);
+                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (unsigned)c->refine_blocks_per_cu;
                 hipLaunchKernelGGL(k_pitch_refine<8>, dim3(blocks), dim3(256), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
                                    list_cap, c->pi_cand.as<double>());   // (4 lanes per candidate measured slower: 1.66 against 1.35 ms)
             }

@@ -1239,6 +1239,7 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
         for (int cand : {4, 3, 2}) if (wt % cand == 0) { wsn = cand; break; }
         const int wsm = 16;
         dim3 wgrid((unsigned)wt, (unsigned)(div_up(M, G_BM * wsm) * wsm), (unsigned)batch);
+        KernelTimer kt(c, PCE_K_GEMM_WIDE, nullptr, 2.0 * M * (double)N * K * batch);
         hipLaunchKernelGGL((k_gemm_wide<EPI>), wgrid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
                            v_col0, vt_sp, wsn, wsm);
         return;
@@ -1251,8 +1252,11 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
         const size_t nblk = (size_t)grid.x * grid.y;
         (void)hipMalloc(&g_gemm_trace, nblk * 32); (void)hipMemsetAsync(g_gemm_trace, 0, nblk * 32, c->stream);
     }
-    hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
-                       v_col0, vt_sp, sn, sm, g_gemm_trace);
+    {
+        KernelTimer kt(c, PCE_K_GEMM128, nullptr, 2.0 * M * (double)N * K * batch);
+        hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
+                           v_col0, vt_sp, sn, sm, g_gemm_trace);
+    }
     if (want_trace) {
         const size_t nblk = (size_t)grid.x * grid.y;
         std::vector<unsigned long long> h(nblk * 4);
@@ -1489,8 +1493,11 @@ int pce_whisper_encode_run(pce_ctx *c)
                                   Wf + w->c2_b, w->resid.as<float>(), d, (int64_t)W_CTX * d, n, w->pos.as<float>(), W_CTX);
     for (int l = 0; l < L; l++) {
         const WhisperState::Layer &ly = w->layers[(size_t)l];
-        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln1_w,
-                           Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
+        {
+            KernelTimer kt(c, PCE_K_LAYERNORM);
+            hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln1_w,
+                               Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
+        }
         // Q | K go to the row-major [M][2d] buffer, V is written transposed per head (pos carries the pointer)
         launch_gemm<EPI_QKV>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 2 * d, 0, 1,
                              reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX, 2 * d, AT_SP);
@@ -1500,16 +1507,23 @@ int pce_whisper_encode_run(pce_ctx *c)
             a.vt = w->vt.as<bf16>(); a.vt_clip = (int64_t)d * AT_SP; a.vt_sp = AT_SP;
             a.q_row0 = a.k_row0 = w->enc_tab.as<int>(); a.q_len = a.k_len = w->enc_tab.as<int>() + n;
             a.out = w->attn.as<bf16>(); a.out_ld = d; a.causal = 0;
+            KernelTimer kt(c, PCE_K_ATTENTION, nullptr, 4.0 * W_CTX * (double)W_CTX * d * n);
             hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
         }
         launch_gemm<EPI_RESID_F32>(c, w->attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, w->resid.as<float>(), d, 0, 1);
-        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln2_w,
-                           Wf + ly.ln2_b, M, d, w->ln_out.as<bf16>());
+        {
+            KernelTimer kt(c, PCE_K_LAYERNORM);
+            hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln2_w,
+                               Wf + ly.ln2_b, M, d, w->ln_out.as<bf16>());
+        }
         launch_gemm<EPI_GELU_BF16>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.m1_w, (int)M, 4 * d, d, Wf + ly.m1_b, w->hidden.as<bf16>(), 4 * d, 0, 1);
         launch_gemm<EPI_RESID_F32>(c, w->hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, (int)M, d, 4 * d, Wf + ly.m2_b, w->resid.as<float>(), d, 0, 1);
     }
-    hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + w->lnp_w,
-                       Wf + w->lnp_b, M, d, w->final_out.as<float>());
+    {
+        KernelTimer kt(c, PCE_K_LAYERNORM);
+        hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + w->lnp_w,
+                           Wf + w->lnp_b, M, d, w->final_out.as<float>());
+    }
     PCE_HIP(c, hipGetLastError());
     w->n_clips_enc = n; w->g_xkv_clips = -1; w->g_cache_len = -1;
     return PCE_OK;

@@ -90,7 +90,8 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
+              "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -103,7 +104,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
-           "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_kernel_name"]
+           "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
 
 
 def load_library() -> C.CDLL:
@@ -161,6 +162,7 @@ def load_library() -> C.CDLL:
     lib.pce_profile_enable.argtypes = [vp, C.c_int]
     lib.pce_profile_reset.argtypes = [vp]
     lib.pce_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.pce_profile_get_work.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.pce_kernel_name.argtypes = [C.c_int]; lib.pce_kernel_name.restype = C.c_char_p
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -537,7 +539,9 @@ class ProsodyEngine:
             ms = C.c_double(); n = C.c_int64()
             self._check(self._lib.pce_profile_get(self._ctx, i, C.byref(ms), C.byref(n)))
             if n.value:
-                out[name] = {"total_ms": ms.value, "launches": n.value}
+                fl = C.c_double()
+                self._check(self._lib.pce_profile_get_work(self._ctx, i, C.byref(fl)))
+                out[name] = {"total_ms": ms.value, "launches": n.value, "flops": fl.value}
         return out
 
 

@@ -5,13 +5,17 @@ the segment-sorted utterance list (Code/audioPipeline.py:364-367 order) and neve
 the data path.  Only the baselines (sliding medians, Code/audioPipeline.py:401-424) and the
 EMA smoothing (:592-602) need every segment's scalars: one all-gather of fixed-width fp64
 records (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  Payload is a
-few hundred KB at most, so a single padded all-gather beats anything ring-tuned.
+few hundred KB at most, so a single padded all-gather beats anything ring-tuned.  The row counts of every rank
+follow from ``shard_range`` (and, for syntagmes, from the TextGrids every rank can read), so nothing but the
+records themselves is exchanged.
 """
 from __future__ import annotations
 
 import numpy as np
 
 SEGMENT_RECORD = ("p_nat", "l_nat", "l_syn", "d_nat", "d_syn", "wc", "rate_ratio")   # Code/audioPipeline.py:391-400
+SYNTAGME_RECORD = ("seg_idx", "p_nat", "l_syn", "nat_total", "syn_total", "pause_ms", "wc_syn")   # measured at :499-523
+RECORD_WIDTH = 1 + max(len(SEGMENT_RECORD), len(SYNTAGME_RECORD))   # column 0: 0 = segment row, 1 = syntagme row
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -21,10 +25,14 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allgather_records(local: np.ndarray, device=None) -> np.ndarray:
-    """All-gather ragged per-rank record blocks ``[n_local, width]`` (float64) into
-    ``[n_total, width]`` in rank order.  One collective for the counts is avoided by padding
-    to the maximum block size carried in the record header row."""
+def allgather_records(local: np.ndarray, counts=None, device=None) -> np.ndarray:
+    """All-gather ragged per-rank record blocks ``[n_local, width]`` (float64) into ``[n_total, width]`` in rank order
+    with ONE collective (``all_gather_into_tensor``; RCCL over xGMI when the backend is "nccl").
+
+    ``counts``: rows every rank contributes, known to all ranks without talking -- ``shard_range`` sizes for
+    per-utterance records, TextGrid-derived syntagme counts for the tagger.  Blocks are padded to ``max(counts)``.
+    Without ``counts`` the block sizes have to be agreed on first (one extra scalar MAX all-reduce; the row count then
+    rides in a header row): callers on the hot path always pass ``counts``."""
     import torch
     import torch.distributed as dist
 
@@ -32,21 +40,32 @@ def allgather_records(local: np.ndarray, device=None) -> np.ndarray:
     if local.ndim != 2:
         raise ValueError("records must be [n, width]")
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if counts is not None and int(counts[0]) != local.shape[0]:
+            raise ValueError(f"rank 0 holds {local.shape[0]} records, counts says {counts[0]}")
         return local.copy()
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     width = local.shape[1]
-    # counts ride along in one extra header row, so a single collective moves everything
-    cap = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
-    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-    cap = int(cap.item())
-    block = torch.zeros((cap + 1, width), dtype=torch.float64, device=device)
-    block[0, 0] = float(local.shape[0])
+    header = 0
+    if counts is None:
+        cap = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        cap, header = int(cap.item()), 1
+    else:
+        counts = [int(c) for c in counts]
+        if len(counts) != world or counts[rank] != local.shape[0]:
+            raise ValueError(f"rank {rank} holds {local.shape[0]} records, counts = {counts}")
+        cap = max(counts) if counts else 0
+    block = torch.zeros((cap + header, width), dtype=torch.float64, device=device)
+    if header:
+        block[0, 0] = float(local.shape[0])
     if local.shape[0]:
-        block[1:1 + local.shape[0]] = torch.from_numpy(local).to(device)
-    out = torch.empty((world * (cap + 1), width), dtype=torch.float64, device=device)
+        block[header:header + local.shape[0]] = torch.from_numpy(local).to(device)
+    out = torch.empty((world * (cap + header), width), dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(out, block)
-    out = out.cpu().numpy().reshape(world, cap + 1, width)
-    parts = [out[r, 1:1 + int(out[r, 0, 0])] for r in range(world)]
+    out = out.cpu().numpy().reshape(world, cap + header, width)
+    if header:
+        counts = [int(out[r, 0, 0]) for r in range(world)]
+    parts = [out[r, header:header + counts[r]] for r in range(world)]
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, width))

@@ -245,14 +245,13 @@ class SsmlTagger:
     def syntagmes_of(self, seg: SegmentInput) -> List[dict]:
         return build_syntagmes(clean_sequence(words_and_pauses(seg.intervals), self.nlp, self.s.end_punctuation_pause_ms))
 
-    def raw_rows(self, segments: Sequence[SegmentInput], base: Sequence[dict], src: MeasurementSource) -> List[dict]:
-        s = self.s
-        P_ST, R_PCT = s.pitch_semitones, s.rate_percent
-        rows = []
-        for seg, b in zip(segments, base):
+    def syntagme_measurements(self, segments: Sequence[SegmentInput], src: MeasurementSource) -> List[dict]:
+        """Everything Code/audioPipeline.py:499-523 MEASURES per syntagme (no baseline enters yet): these are the
+        per-syntagme records of the multi-GPU exchange."""
+        meas = []
+        for seg in segments:
             for syn in self.syntagmes_of(seg):
                 t0, t1 = syn["start_ms"] / 1000, syn["end_ms"] / 1000
-                wc_syn = len(syn["words"].split())
                 p_nat = src.median_pitch(seg.name, t0, t1)
                 src.lufs("nat", seg.name, t0, t1)               # measured by the reference too (value unused)
                 try:
@@ -261,42 +260,58 @@ class SsmlTagger:
                 except CouldntDecodeError:
                     l_syn = src.lufs("nat", seg.name, t0, t1)
                     syn_total = src.part_duration("nat", seg.name, t0, t1)
-                pause_s = syn["pause_ms"] / 1000.0
                 nat_total = src.part_duration("nat", seg.name, t0, t1)
-                d_nat = max(nat_total - pause_s, 1e-4)
-                d_syn = max(syn_total - pause_s, 1e-4)
+                meas.append({"segment": seg.name, "syntagme": syn["words"], "pause_ms": syn["pause_ms"], "p_nat": p_nat, "l_syn": l_syn,
+                             "nat_total": nat_total, "syn_total": syn_total, "wc_syn": len(syn["words"].split())})
+        return meas
 
-                if p_nat > 0:
-                    st = 12 * np.log2(p_nat / b["f0"])
-                    st = np.clip(st, -P_ST * s.pitch_lower_clip_factor, P_ST)
-                    p_pct = (2 ** (st / 12) - 1) * 100
-                else:
-                    p_pct = 0.0
+    def rows_from_measurements(self, meas: Sequence[dict], base_of: dict) -> List[dict]:
+        """The closed-form adjustment formulas of Code/audioPipeline.py:524-577 on measured syntagmes; ``base_of``:
+        segment name -> its baselines."""
+        s = self.s
+        P_ST, R_PCT = s.pitch_semitones, s.rate_percent
+        rows = []
+        for m in meas:
+            b = base_of[m["segment"]]
+            p_nat, l_syn, wc_syn = m["p_nat"], m["l_syn"], m["wc_syn"]
+            pause_s = m["pause_ms"] / 1000.0
+            d_nat = max(m["nat_total"] - pause_s, 1e-4)
+            d_syn = max(m["syn_total"] - pause_s, 1e-4)
 
-                db_diff = b["loud"] - l_syn
-                v_pct = (10 ** (db_diff / 20) - 1.0) * 100.0
-                v_pct = np.clip(v_pct, -s.volume_pct, +s.volume_pct)
+            if p_nat > 0:
+                st = 12 * np.log2(p_nat / b["f0"])
+                st = np.clip(st, -P_ST * s.pitch_lower_clip_factor, P_ST)
+                p_pct = (2 ** (st / 12) - 1) * 100
+            else:
+                p_pct = 0.0
 
-                if wc_syn > 0:
-                    nat_r, syn_r = wc_syn / d_nat, wc_syn / d_syn
-                    rp = (nat_r - syn_r) / syn_r * 100
-                else:
-                    rp = 0.0
-                length_s = d_nat
-                if length_s <= 1.0:
-                    slow_factor = fast_factor = 1.0
-                else:
-                    slow_factor, fast_factor = length_s ** 1.5, np.sqrt(length_s)
-                rp = rp * slow_factor if rp < 0 else rp / fast_factor
-                rp = rp - max(0.0, length_s - s.threshold_duration_before_slowing_down) * s.slow_floor_per_sec
-                if length_s > 5.0:
-                    max_slow, max_fast = R_PCT * 1.5, R_PCT * 0.5
-                else:
-                    max_slow, max_fast = R_PCT, R_PCT
-                rp = np.clip(rp, -max_slow, +max_fast)
-                rows.append({"segment": seg.name, "syntagme": syn["words"], "pause": syn["pause_ms"],
-                             "raw_pitch": float(p_pct), "raw_volume": float(v_pct), "raw_rate": float(rp)})
+            db_diff = b["loud"] - l_syn
+            v_pct = (10 ** (db_diff / 20) - 1.0) * 100.0
+            v_pct = np.clip(v_pct, -s.volume_pct, +s.volume_pct)
+
+            if wc_syn > 0:
+                nat_r, syn_r = wc_syn / d_nat, wc_syn / d_syn
+                rp = (nat_r - syn_r) / syn_r * 100
+            else:
+                rp = 0.0
+            length_s = d_nat
+            if length_s <= 1.0:
+                slow_factor = fast_factor = 1.0
+            else:
+                slow_factor, fast_factor = length_s ** 1.5, np.sqrt(length_s)
+            rp = rp * slow_factor if rp < 0 else rp / fast_factor
+            rp = rp - max(0.0, length_s - s.threshold_duration_before_slowing_down) * s.slow_floor_per_sec
+            if length_s > 5.0:
+                max_slow, max_fast = R_PCT * 1.5, R_PCT * 0.5
+            else:
+                max_slow, max_fast = R_PCT, R_PCT
+            rp = np.clip(rp, -max_slow, +max_fast)
+            rows.append({"segment": m["segment"], "syntagme": m["syntagme"], "pause": m["pause_ms"],
+                         "raw_pitch": float(p_pct), "raw_volume": float(v_pct), "raw_rate": float(rp)})
         return rows
+
+    def raw_rows(self, segments: Sequence[SegmentInput], base: Sequence[dict], src: MeasurementSource) -> List[dict]:
+        return self.rows_from_measurements(self.syntagme_measurements(segments, src), {seg.name: b for seg, b in zip(segments, base)})
 
     # -- step 4: EMA + jump limit over all syntagmes, in order
     def smooth(self, rows: Sequence[dict]):
@@ -343,37 +358,49 @@ class SsmlTagger:
                     for seg, pieces in by_seg.items()]
         return pd.DataFrame(seg_rows), pd.DataFrame(syn_rows), pd.DataFrame(synth_rows)
 
-    # -- multi-GPU: utterances sharded by rank, exactly one exchange per table
+    # -- multi-GPU: utterances sharded by rank, exactly ONE exchange
     def run_sharded(self, segments: Sequence[SegmentInput], src: MeasurementSource, rank: int, world: int,
-                    allgather: Callable[[np.ndarray], np.ndarray]) -> TaggerResult:
+                    allgather: Callable[..., np.ndarray]) -> TaggerResult:
         """Rank ``rank`` of ``world`` measures only its contiguous block of the segment-sorted list
-        (:func:`shard.shard_range`).  Two padded all-gathers of fp64 records move everything the
-        sequential parts need: the 7 per-segment statistics (Code/audioPipeline.py:391-400) before the
-        baselines, and (segment index, pause, raw pitch / volume / rate) per syntagme before the EMA
-        smoothing, which runs over ALL syntagmes in segment order (:592-602).  Texts are not
-        exchanged: every rank can rebuild them from the TextGrids.  Every rank returns the full tables."""
-        from .shard import SEGMENT_RECORD, shard_range
+        (:func:`shard.shard_range`): the 7 per-segment statistics (Code/audioPipeline.py:391-400) and the per-syntagme
+        measurements (:499-523).  Baselines only enter the closed-form formulas AFTER all measurements (:526, :535), so
+        ONE all-gather of fp64 records (segment rows and syntagme rows in the same padded block, told apart by column
+        0) moves everything; baselines, adjustments, the EMA over ALL syntagmes in segment order (:592-602) and the
+        SSML strings are then computed by every rank.  Row counts per rank follow from ``shard_range`` and from the
+        TextGrids (every rank reads all of them: texts are not exchanged), so the collective carries records only.
+        ``allgather(local, counts)``: :func:`shard.allgather_records`.  Every rank returns the full tables."""
+        from .shard import RECORD_WIDTH, SEGMENT_RECORD, SYNTAGME_RECORD, shard_range
         segments = sorted(segments, key=lambda s: segment_sort_key(s.name))
-        lo, hi = shard_range(len(segments), rank, world)
+        syn_of = [self.syntagmes_of(seg) for seg in segments]                   # host only: TextGrids + POS table
+        spans = [shard_range(len(segments), r, world) for r in range(world)]
+        counts = [(b - a) + sum(len(syn_of[i]) for i in range(a, b)) for a, b in spans]
+        lo, hi = spans[rank]
         mine = segments[lo:hi]
         res = TaggerResult()
         local = self.segment_statistics(mine, src)
-        rec = np.array([[s[k] for k in SEGMENT_RECORD] for s in local], dtype=np.float64).reshape(len(local), len(SEGMENT_RECORD))
-        allrec = allgather(rec)
-        res.segment_stats = [dict(zip(SEGMENT_RECORD, map(float, r)), segment=segments[i].name) for i, r in enumerate(allrec)]
+        meas = self.syntagme_measurements(mine, src)
+        index = {s.name: i for i, s in enumerate(segments)}
+        rec = np.zeros((len(local) + len(meas), RECORD_WIDTH), dtype=np.float64)
+        for k, st in enumerate(local):
+            rec[k, 1:1 + len(SEGMENT_RECORD)] = [st[f] for f in SEGMENT_RECORD]
+        for k, m in enumerate(meas, start=len(local)):
+            rec[k, 0] = 1.0
+            rec[k, 1:1 + len(SYNTAGME_RECORD)] = [index[m["segment"]]] + [m[f] for f in SYNTAGME_RECORD[1:]]
+        allrec = allgather(rec, counts)
+        seg_rec, syn_rec = allrec[allrec[:, 0] == 0.0], allrec[allrec[:, 0] == 1.0]
+        texts = [(i, syn["words"]) for i, syns in enumerate(syn_of) for syn in syns]
+        if len(seg_rec) != len(segments) or len(texts) != len(syn_rec) or any(int(r[1]) != i for r, (i, _) in zip(syn_rec, texts)):
+            raise RuntimeError("gathered records do not match the TextGrids")
+        res.segment_stats = [dict(zip(SEGMENT_RECORD, map(float, r[1:1 + len(SEGMENT_RECORD)])), segment=segments[i].name)
+                             for i, r in enumerate(seg_rec)]
         for s in res.segment_stats:
             s["wc"] = int(s["wc"])
         res.baselines = self.baselines(res.segment_stats)
-        rows_local = self.raw_rows(mine, res.baselines[lo:hi], src)
-        index = {s.name: i for i, s in enumerate(segments)}
-        num = np.array([[index[r["segment"]], r["pause"], r["raw_pitch"], r["raw_volume"], r["raw_rate"]] for r in rows_local],
-                       dtype=np.float64).reshape(len(rows_local), 5)
-        allnum = allgather(num)
-        texts = [syn["words"] for seg in segments for syn in self.syntagmes_of(seg)]
-        if len(texts) != len(allnum):
-            raise RuntimeError("gathered syntagme table does not match the TextGrids")
-        res.rows = [{"segment": segments[int(r[0])].name, "syntagme": t, "pause": int(r[1]), "raw_pitch": float(r[2]),
-                     "raw_volume": float(r[3]), "raw_rate": float(r[4])} for r, t in zip(allnum, texts)]
+        all_meas = [dict(zip(SYNTAGME_RECORD[1:], map(float, r[2:1 + len(SYNTAGME_RECORD)])), segment=segments[i].name, syntagme=t)
+                    for r, (i, t) in zip(syn_rec, texts)]
+        for m in all_meas:
+            m["pause_ms"], m["wc_syn"] = int(m["pause_ms"]), int(m["wc_syn"])
+        res.rows = self.rows_from_measurements(all_meas, {seg.name: b for seg, b in zip(segments, res.baselines)})
         if res.rows:
             res.smooth_pitch, res.smooth_rate = self.smooth(res.rows)
             res.bdd_ssml, res.bdd_syntagme_ssml, res.bdd_syntagme_for_synth = self.tables(res.rows, res.smooth_pitch, res.smooth_rate)

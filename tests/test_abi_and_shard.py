@@ -74,8 +74,15 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 n = 11
 lo, hi = shard.shard_range(n, rank, world)
 full = np.arange(n * 7, dtype=np.float64).reshape(n, 7) * 0.5 - 3.0
-got = shard.allgather_records(full[lo:hi])
+counts = [b - a for a, b in (shard.shard_range(n, r, world) for r in range(world))]
+got = shard.allgather_records(full[lo:hi], counts)          # the hot-path form: one collective, nothing but records
 assert got.shape == (n, 7) and np.array_equal(got, full), got
+got = shard.allgather_records(full[lo:hi])                  # sizes unknown: header row + one scalar all-reduce
+assert got.shape == (n, 7) and np.array_equal(got, full), got
+try:
+    shard.allgather_records(full[lo:hi], [c + 1 for c in counts]); raise SystemExit("wrong counts accepted")
+except ValueError:
+    pass
 empty = shard.allgather_records(np.zeros((0 if rank else 2, 3)))
 assert empty.shape == (2, 3)
 dist.barrier(); dist.destroy_process_group()
@@ -104,7 +111,18 @@ from test_goldens import FixtureSource, load
 rank, world = int(sys.argv[1]), int(sys.argv[2])
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
 dist.init_process_group("gloo", rank=rank, world_size=world)
+calls = []
+_orig = dist.all_gather_into_tensor
+def _counting(*a, **k):
+    calls.append(1); return _orig(*a, **k)
+dist.all_gather_into_tensor = _counting
+_ar = dist.all_reduce
+def _no_allreduce(*a, **k):
+    raise AssertionError("the sharded tagger must not all-reduce")
+dist.all_reduce = _no_allreduce
+n_scen = 0
 for sc in load("tagger.json"):
+    n_scen += 1
     tg = T.SsmlTagger(T.ProsodySettings.from_config(sc["config"]), sc["azure_voice"], nlp=T.TablePosTagger(sc["pos_table"]))
     segs = [T.SegmentInput(s["segment"], [tuple(iv) for iv in s["intervals"]]) for s in sc["segments"]]
     res = tg.run_sharded(segs, FixtureSource(sc), rank, world, shard.allgather_records)
@@ -113,13 +131,15 @@ for sc in load("tagger.json"):
         path = os.path.join(sys.argv[5], f"r{rank}_{name}")
         df.to_csv(path, index=False)
         assert open(path, encoding="utf-8").read() == sc["expected"][name], (rank, name)
+assert len(calls) == n_scen, (len(calls), n_scen)             # exactly one collective per tagger run
+dist.all_reduce = _ar
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
 def test_sharded_tagger_reproduces_reference_csvs_gloo_world2(tmp_path):
-    """N > 1 path of the SSML tagger: two ranks each measure half of the segments, two all-gathers,
+    """N > 1 path of the SSML tagger: two ranks each measure half of the segments, ONE all-gather (counted below),
     and the CSVs equal the reference's (golden G7) on every rank."""
     script = tmp_path / "t.py"
     script.write_text(_TAGGER_WORKER)
@@ -129,3 +149,19 @@ def test_sharded_tagger_reproduces_reference_csvs_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no rendezvous in the environment starts two rank processes itself and rank 0
+    prints the line with n_gpus = 2 (launcher + exchange on CPU: gloo, no engine)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "7", "--selftest-launcher"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["exchange_ok"] and line["records"] == 14
+    # a rank whose WORLD_SIZE contradicts --gpus refuses to run instead of silently reporting n_gpus = 1
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-launcher"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert bad.returncode != 0 and b"WORLD_SIZE" in bad.stderr
