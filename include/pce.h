@@ -128,7 +128,13 @@ int pce_energy_fetch(pce_ctx *ctx, pce_energy *out /* n_slices */);
  * by get_lufs (Code/audioPipeline.py:338-358): peak normalisation, K-weighting
  * biquads designed for the batch's sample rate, 400 ms / 75 % blocks, -70 LKFS and
  * -10 LU gates.  status[i] = PCE_SLICE_TOO_SHORT where pyloudnorm raises
- * ValueError (n < 0.4 * rate); the whole-file fallback is the caller's. */
+ * ValueError (n < 0.4 * rate); the whole-file fallback is the caller's.
+ * pce_lufs_set_meter_rate: the reference builds ONE meter from the natural recording's frame rate
+ * (Code/audioPipeline.py:372,493: pyln.Meter(AudioSegment.from_file(wav).frame_rate)) and measures the raw synthesis with
+ * it as well, whatever that file's own rate is (Azure's default RIFF output is 16 kHz, the recordings are 44.1 kHz):
+ * filter design, the 0.4 s block length in samples and the too-short test all use the METER's rate.  rate > 0 makes
+ * the following pce_lufs_run calls do the same; 0 (default) = the batch's rate. */
+int pce_lufs_set_meter_rate(pce_ctx *ctx, int32_t rate);
 int pce_lufs_run(pce_ctx *ctx, const pce_slice *slices, int32_t n_slices);
 int pce_lufs_fetch(pce_ctx *ctx, double *lufs /* n_slices */, int32_t *status /* n_slices */);
 
@@ -267,6 +273,27 @@ typedef struct pce_whisper_decode_rules { int32_t eot, timestamp_begin, max_init
 int pce_whisper_decode_step(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets /* [clips + 1] */, int32_t sample_begin,
                             const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens /* [clips] */,
                             float *next_logprobs /* [clips] or NULL: log-probability of the choice under the filtered distribution (sum_logprobs) */);
+/* The same step with the per-sequence controls whisper.transcribe needs around it (transcribe.py decode_with_fallback,
+ * decoding.py DecodingTask): every sequence has its own prompt length (condition_on_previous_text prepends
+ * <|startofprev|> + the previous windows' text), a temperature > 0 draws ONE sample from softmax(filtered logits /
+ * temperature) as GreedyDecoder does (Gumbel-max over a counter-based generator keyed by (seed, clip, position): the
+ * same call gives the same draw), and probe_token >= 0 also returns softmax(UNFILTERED logits of the last
+ * position)[probe_token] -- run on the prefix that ends at <|startoftranscript|> this is no_speech_prob.
+ * next_logprobs stays the log-probability at temperature 1 under the filtered distribution (sum_logprobs).
+ * Sequences of different lengths keep their self-attention K / V cache: a call whose every prefix extends the
+ * previous call's by exactly one token appends one position per sequence. */
+typedef struct pce_whisper_decode_opts {
+    const int32_t *sample_begin;   /* [clips] first sampled position of every sequence, or NULL: sample_begin_all for all */
+    int32_t sample_begin_all;
+    float temperature;             /* 0: arg-max (first maximum) */
+    uint32_t seed_lo, seed_hi;
+    int32_t probe_token;           /* < 0: no probe */
+    int32_t reserved;
+} pce_whisper_decode_opts;
+int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets /* [clips + 1] */,
+                               const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts,
+                               int32_t *next_tokens /* [clips] */, float *next_logprobs /* [clips] or NULL */,
+                               float *probe_prob /* [clips] or NULL */);
 
 /* ---- R8: dynamic time warping (alignment indices) ------------------------
  * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on

@@ -3,8 +3,8 @@
 
 The array work of a step -- text decoder, output projection, the logit filters SuppressBlank / SuppressTokens /
 ApplyTimestampRules and the arg-max -- is ``ProsodyEngine.whisper_decode_step`` (libpce.so).  Here: the prompt, the
-vocabulary mask the filters read, the loop and its stopping rule.  Token ids in and out: turning text into ids and back
-needs the checkpoint's tiktoken vocabulary, which is not reachable offline."""
+vocabulary mask the filters read, the loop and its stopping rule.  Token ids in and out: ``Aligners/tokenizer.py`` turns ids into text given the checkpoint's
+vocabulary file, ``Aligners/transcribe.py`` drives the windows of a recording (prompts, thresholds, word timings)."""
 from __future__ import annotations
 
 import numpy as np
@@ -44,6 +44,49 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
         out.append(s[:begin + cut])
     greedy_decode.last_sum_logprobs = sum_logprobs                  # avg_logprob of transcribe = sum / (tokens + 1)
     return out
+
+
+def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, sample_len: int, temperature: float = 0.0, seed: int = 0,
+                 active=None):
+    """``greedy_decode`` with one prompt per clip (``condition_on_previous_text`` gives every recording its own) and an
+    optional temperature (GreedyDecoder at temperature t: one sample per step from softmax(filtered logits / t)).
+    ``active[i]`` False: the clip is left alone (it reads as ended from the first step on).
+    -> (sampled tokens per clip, end-of-text cut off; their log-probabilities per clip; sum_logprobs [clips])."""
+    n = engine.whisper_num_encoded()
+    eot = rules["eot"]
+    active = [True] * n if active is None else list(active)
+    seqs = [list(p) if a else list(p) + [eot] for p, a in zip(prompts, active)]
+    begins = np.asarray([b if a else b for b, a in zip(sample_begins, active)], dtype=np.int32)
+    mask = vocab_mask(n_vocab, rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    lps = [[] for _ in range(n)]
+    for _ in range(sample_len):
+        nxt, lp, _ = engine.whisper_decode_step_ex(seqs, begins, eot, rules["timestamp_begin"], mask, rules.get("max_initial_timestamp_index"),
+                                                   temperature=temperature, seed=seed)
+        for i in range(n):
+            ended = seqs[i][-1] == eot and len(seqs[i]) > begins[i]
+            seqs[i].append(int(nxt[i]))
+            if not ended:
+                lps[i].append(float(lp[i]))
+        if all(s[-1] == eot for s in seqs):
+            break
+    out_t, out_lp = [], []
+    for i in range(n):
+        new = seqs[i][int(begins[i]):] if active[i] else []
+        cut = new.index(eot) if eot in new else len(new)
+        out_t.append(new[:cut])
+        out_lp.append(lps[i][:cut + (1 if eot in new else 0)] if active[i] else [])        # (the end-of-text token's own term is part of sum_logprobs)
+    sums = np.array([float(np.sum(l)) if l else 0.0 for l in out_lp])
+    return out_t, [l[:len(t)] for l, t in zip(out_lp, out_t)], sums
+
+
+def no_speech_probs(engine, n_vocab: int, prompts, sot_index, rules: dict, no_speech_token: int):
+    """``probs_at_sot[:, tokenizer.no_speech]`` of DecodingTask._main_loop: the decoder is causal, so the distribution at the
+    <|startoftranscript|> position of a prompt equals the last position of the prefix that ends there."""
+    mask = vocab_mask(n_vocab, rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    prefixes = [list(p[:k + 1]) for p, k in zip(prompts, sot_index)]
+    _, _, probe = engine.whisper_decode_step_ex(prefixes, [len(p) for p in prefixes], rules["eot"], rules["timestamp_begin"], mask,
+                                                rules.get("max_initial_timestamp_index"), probe_token=int(no_speech_token))
+    return np.asarray(probe, dtype=np.float64)
 
 
 # ---------------------------------------------------------------------------------------------------------------

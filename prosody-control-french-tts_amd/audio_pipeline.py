@@ -8,12 +8,17 @@ names (Code/audioPipeline.py:84-153, :1076-1103), same output artefacts
 once, and every whole-file and per-syntagme pitch / loudness query becomes one slice of three
 batched GPU passes (:class:`EngineMeasurements`).  The decision logic lives in :mod:`.tagger`.
 
-Steps that are not on the hot path (Azure synthesis, demucs, JSON export, break comparison)
-are not reimplemented: selecting them raises ``NotImplementedError`` naming the step.
+The two Whisper steps (``"Align+Transcribe"``, ``"Final Transcribe"``, :179-241 and :856-892) run the batched
+aligner of :mod:`.Aligners.use_whisper_timestamped` and leave the reference's folders.  Steps that are not on the hot
+path (demucs, Azure synthesis, JSON export, break comparison: SURVEY.md section 8 marks them out of scope) are not
+reimplemented: ``run()`` skips them with a warning unless ``strict_steps: true`` is set (additive config key), in
+which case selecting one fails at construction.
 """
 from __future__ import annotations
 
+import json
 import logging
+import shutil
 import sys
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -27,116 +32,227 @@ from .textgrid_io import read_textgrid
 
 STEP_NAMES = ["Preprocess", "Align+Transcribe", "Raw Synthesis", "Measure & Build SSML", "Synthesize+Merge",
               "Export JSON", "Final Transcribe", "Compare Breaks"]                    # Code/audioPipeline.py:1077-1086
+ACCELERATED_STEPS = ("Align+Transcribe", "Measure & Build SSML", "Final Transcribe")
 
 
-class EngineMeasurements(MeasurementSource):
-    """Answers the tagger's queries from batched GPU passes over a resident batch.
+class BatchedMeasurements:
+    """Decoded files (any hashable key) + planned pitch / loudness queries -> batched GPU passes.
 
-    ``files``: {(kind, segment): path} with kind "nat"/"syn".  Every decodable file becomes a
-    clip; ``plan`` collects the (segment, t0, t1) queries the tagger will make, ``run`` executes
-    them (pitch: Praat ``extract_part`` sample rule; loudness: pydub ms rule + the reference's
-    whole-file fallbacks, decided on the host from the slice length)."""
+    Files are uploaded as one resident batch per sample rate.  A loudness query names the rate of the ``pyln.Meter`` the
+    reference would hand to ``get_lufs``: filter design, block length and the too-short test follow the METER's rate, not
+    the data's (``ProsodyEngine.lufs_set_meter_rate``).  Queries that were not planned are answered on demand (a batch of
+    one): correct, but the point of planning is that a voice costs a handful of launches."""
 
-    def __init__(self, engine: ProsodyEngine, files: Dict[Tuple[str, str], Path], pitch_floor=150.0, pitch_ceiling=600.0):
+    def __init__(self, engine: ProsodyEngine, pitch_floor=150.0, pitch_ceiling=600.0):
         self.eng = engine
         self.floor, self.ceiling = pitch_floor, pitch_ceiling
-        self.clip_of: Dict[Tuple[str, str], int] = {}
-        self.n_frames: Dict[Tuple[str, str], int] = {}
+        self.n_frames: Dict[object, int] = {}
+        self.rate_of: Dict[object, int] = {}
+        self._pcm: Dict[object, np.ndarray] = {}
         self.undecodable = set()
-        clips, rates = [], set()
-        for key, path in files.items():
-            try:
-                rate, pcm = H.decode_wav(path)
-            except H.CouldntDecodeError:
-                self.undecodable.add(key)
-                continue
-            self.clip_of[key] = len(clips); self.n_frames[key] = len(pcm)
-            clips.append(pcm); rates.add(rate)
-        if len(rates) > 1:
-            raise ValueError(f"all files of a voice must share one sample rate, found {sorted(rates)}")
-        self.rate = rates.pop() if rates else 0
-        if clips:
-            engine.upload(clips, self.rate)
-        self._pitch: Dict[Tuple[str, Optional[float], Optional[float]], float] = {}
-        self._lufs: Dict[Tuple[str, str, Optional[int], Optional[int]], float] = {}
-        self._pq: List[Tuple[str, Optional[float], Optional[float]]] = []
-        self._lq: List[Tuple[str, str, Optional[int], Optional[int]]] = []
+        self._pitch: Dict[tuple, float] = {}
+        self._lufs: Dict[tuple, float] = {}
+        self._pq: List[tuple] = []
+        self._lq: List[tuple] = []
+
+    def add_file(self, key, path) -> bool:
+        if key in self.rate_of or key in self.undecodable:
+            return key in self.rate_of
+        try:
+            rate, pcm = H.decode_wav(path)
+        except H.CouldntDecodeError:
+            self.undecodable.add(key)
+            return False
+        self.n_frames[key] = len(pcm); self.rate_of[key] = rate; self._pcm[key] = pcm
+        return True
 
     # ------------------------------------------------------------------ planning
-    def plan_pitch(self, segment, t0=0.0, t1=None):
-        self._pq.append((segment, None, None) if t1 is None else (segment, t0, t1))
+    @staticmethod
+    def _pq_key(key, t0, t1):
+        return (key, None, None) if t1 is None else (key, t0, t1)
 
-    def plan_lufs(self, kind, segment, t0=0.0, t1=None):
-        if (kind, segment) in self.clip_of:
-            self._lq.append((kind, segment, None, None) if t1 is None else (kind, segment, int(t0 * 1000), int(t1 * 1000)))
+    @staticmethod
+    def _lq_key(key, t0, t1, meter):
+        return (key, None, None, int(meter)) if t1 is None else (key, int(t0 * 1000), int(t1 * 1000), int(meter))
 
-    def _lufs_frames(self, kind, segment, a, b):
-        """Slice to measure for ``audio[a:b]`` including the reference's fallbacks (None = whole file)."""
-        n = self.n_frames[(kind, segment)]
+    def plan_pitch_key(self, key, t0=0.0, t1=None):
+        self._pq.append(self._pq_key(key, t0, t1))
+
+    def plan_lufs_key(self, key, t0, t1, meter_rate):
+        if key in self.rate_of:
+            self._lq.append(self._lq_key(key, t0, t1, meter_rate))
+
+    def _lufs_frames(self, key, a, b, meter_rate):
+        """Slice to measure for ``audio[a:b]`` including the reference's fallbacks (Code/audioPipeline.py:345-358)."""
+        n = self.n_frames[key]
         if a is None:
             return 0, n
-        lo, hi = H.pydub_slice_frames(n, self.rate, a, b)
-        if hi - lo == 0 or hi - lo < 0.4 * self.rate:       # empty slice, or pyloudnorm ValueError -> full segment
+        lo, hi = H.pydub_slice_frames(n, self.rate_of[key], a, b)
+        if hi - lo == 0 or hi - lo < 0.4 * meter_rate:       # empty slice, or pyloudnorm ValueError -> full segment
             return 0, n
         return lo, hi
 
     def run(self):
-        eng, rate = self.eng, self.rate
-        # ---- pitch: Praat extract_part(preserve_times=True) then to_pitch(floor, ceiling)
-        pq = list(dict.fromkeys(self._pq))
-        if pq:
-            cl, b, e, x1 = [], [], [], []
-            for seg, t0, t1 in pq:
-                n = self.n_frames[("nat", seg)]
-                if t1 is None:
-                    bb, ee, xx = 0, n, 0.5 / rate
-                else:
-                    bb, ee, xx = H.praat_part_frames(n, rate, t0, t1, preserve_times=True)
-                cl.append(self.clip_of[("nat", seg)]); b.append(bb); e.append(ee); x1.append(xx)
-            res = eng.pitch(make_slices(cl, b, e, x1), PitchParams.praat(self.floor, self.ceiling), want_f0=False)
-            for q, s in zip(pq, res["summary"]):
-                if s["status"] == SLICE_TOO_SHORT:
-                    # parselmouth raises PraatError here and the reference does not catch it
-                    raise H.PraatError(f"{q[0]}[{q[1]}, {q[2]}]: sound shorter than 3 periods of the pitch floor")
-                self._pitch[q] = float(s["median_f0"])
-        # ---- loudness
-        lq = list(dict.fromkeys(self._lq))
-        if lq:
-            spans = {}
-            for kind, seg, a, b in lq:
-                spans[(kind, seg, a, b)] = (self.clip_of[(kind, seg)],) + self._lufs_frames(kind, seg, a, b)
-            uniq = list(dict.fromkeys(spans.values()))
-            vals, st = eng.lufs(make_slices([u[0] for u in uniq], [u[1] for u in uniq], [u[2] for u in uniq]))
-            table = {}
-            for u, v, code in zip(uniq, vals, st):
-                if code != SLICE_OK:
-                    raise ValueError("Audio must have length greater than the block size.")   # whole file < 0.4 s
-                table[u] = float(v)
-            for q, u in spans.items():
-                self._lufs[q] = table[u]
+        eng = self.eng
+        pq = [q for q in dict.fromkeys(self._pq) if q not in self._pitch]
+        lq = [q for q in dict.fromkeys(self._lq) if q not in self._lufs]
+        lspan = {q: (q[0], q[3]) + self._lufs_frames(q[0], q[1], q[2], q[3]) for q in lq}
+        used = {q[0] for q in pq} | {q[0] for q in lq}
+        for rate in sorted({self.rate_of[k] for k in used}):
+            keys = [k for k in self.rate_of if self.rate_of[k] == rate and k in used]
+            clip = {k: i for i, k in enumerate(keys)}
+            eng.upload([self._pcm[k] for k in keys], rate)
+            # ---- pitch: Praat extract_part(preserve_times=True) then to_pitch(floor, ceiling)
+            mine = [q for q in pq if self.rate_of[q[0]] == rate]
+            if mine:
+                cl, b, e, x1 = [], [], [], []
+                for key, t0, t1 in mine:
+                    n = self.n_frames[key]
+                    if t1 is None:
+                        bb, ee, xx = 0, n, 0.5 / rate
+                    else:
+                        bb, ee, xx = H.praat_part_frames(n, rate, t0, t1, preserve_times=True)
+                    cl.append(clip[key]); b.append(bb); e.append(ee); x1.append(xx)
+                res = eng.pitch(make_slices(cl, b, e, x1), PitchParams.praat(self.floor, self.ceiling), want_f0=False)
+                for q, sm in zip(mine, res["summary"]):
+                    if sm["status"] == SLICE_TOO_SHORT:
+                        # parselmouth raises PraatError here and the reference does not catch it
+                        raise H.PraatError(f"{q[0]}[{q[1]}, {q[2]}]: sound shorter than 3 periods of the pitch floor")
+                    self._pitch[q] = float(sm["median_f0"])
+            # ---- loudness: one pass per meter rate over this batch
+            for meter in sorted({v[1] for v in lspan.values() if self.rate_of[v[0]] == rate}):
+                spans = {q: (clip[v[0]], v[2], v[3]) for q, v in lspan.items() if self.rate_of[v[0]] == rate and v[1] == meter}
+                uniq = list(dict.fromkeys(spans.values()))
+                eng.lufs_set_meter_rate(0 if meter == rate else meter)
+                try:
+                    vals, st = eng.lufs(make_slices([u[0] for u in uniq], [u[1] for u in uniq], [u[2] for u in uniq]))
+                finally:
+                    eng.lufs_set_meter_rate(0)
+                table = {}
+                for u, v, code in zip(uniq, vals, st):
+                    table[u] = float(v) if code == SLICE_OK else None      # None: the whole file is shorter than 0.4 s of the meter's rate
+                for q, u in spans.items():
+                    self._lufs[q] = table[u]
         self._pq.clear(); self._lq.clear()
 
-    # ------------------------------------------------------------------ MeasurementSource
-    def _need(self, kind, segment):
-        if (kind, segment) not in self.clip_of:
-            raise H.CouldntDecodeError(f"{kind}:{segment}")
+    # ------------------------------------------------------------------ answers
+    def _need(self, key):
+        if key not in self.rate_of:
+            raise H.CouldntDecodeError(str(key))
+
+    def pitch_key(self, key, t0=0.0, t1=None) -> float:
+        self._need(key)
+        q = self._pq_key(key, t0, t1)
+        if q not in self._pitch:
+            self._pq.append(q); self.run()
+        return self._pitch[q]
+
+    def lufs_key(self, key, t0, t1, meter_rate) -> float:
+        self._need(key)
+        q = self._lq_key(key, t0, t1, meter_rate)
+        if q not in self._lufs:
+            self._lq.append(q); self.run()
+        v = self._lufs[q]
+        if v is None:
+            raise ValueError("Audio must have length greater than the block size.")      # pyloudnorm, uncaught by the reference's fallback
+        return v
+
+    def duration_key(self, key) -> float:
+        self._need(key)
+        return (self.n_frames[key] / self.rate_of[key]) or 1e-4
+
+    def part_duration_key(self, key, t0=0.0, t1=None) -> float:
+        self._need(key)
+        rate = self.rate_of[key]
+        lo, hi = H.seconds_slice_frames(self.n_frames[key], rate, t0, t1)
+        return ((hi - lo) / rate) or 1e-4
+
+
+class EngineMeasurements(BatchedMeasurements, MeasurementSource):
+    """The tagger's ``MeasurementSource`` over :class:`BatchedMeasurements`.  ``files``: {(kind, segment): path} with kind
+    "nat"/"syn".
+
+    Sample rates: the natural recordings are 44.1 kHz and the raw synthesis is whatever the service returned (Azure's
+    default RIFF output is 16 kHz, Code/Preprocessing/get_synth.py:46-51), so a voice normally mixes rates.  Loudness
+    follows the reference's meters exactly: the segment-level numbers use ONE ``pyln.Meter`` built at the FIRST natural
+    file's rate for natural and synthetic files alike (Code/audioPipeline.py:372), the syntagme-level numbers a meter at
+    the segment's own natural file's rate (:493)."""
+
+    def __init__(self, engine: ProsodyEngine, files: Dict[Tuple[str, str], Path], pitch_floor=150.0, pitch_ceiling=600.0):
+        BatchedMeasurements.__init__(self, engine, pitch_floor, pitch_ceiling)
+        for key, path in files.items():
+            self.add_file(key, path)
+        nat = sorted((k for k in self.rate_of if k[0] == "nat"), key=lambda k: segment_sort_key(k[1]))
+        self.first_nat_rate = self.rate_of[nat[0]] if nat else 0          # the segment-level meter (:372)
+
+    def _meter_rate(self, segment, t1) -> int:
+        if t1 is None:
+            return self.first_nat_rate
+        return self.rate_of.get(("nat", segment), self.first_nat_rate)
+
+    def plan_pitch(self, segment, t0=0.0, t1=None):
+        self.plan_pitch_key(("nat", segment), t0, t1)
+
+    def plan_lufs(self, kind, segment, t0=0.0, t1=None):
+        self.plan_lufs_key((kind, segment), t0, t1, self._meter_rate(segment, t1))
 
     def median_pitch(self, segment, t0=0.0, t1=None):
-        return self._pitch[(segment, None, None) if t1 is None else (segment, t0, t1)]
+        return self.pitch_key(("nat", segment), t0, t1)
 
     def lufs(self, kind, segment, t0=0.0, t1=None):
-        self._need(kind, segment)
-        return self._lufs[(kind, segment, None, None) if t1 is None else (kind, segment, int(t0 * 1000), int(t1 * 1000))]
+        return self.lufs_key((kind, segment), t0, t1, self._meter_rate(segment, t1))
 
     def duration(self, kind, segment):
-        self._need(kind, segment)
-        return (self.n_frames[(kind, segment)] / self.rate) or 1e-4
+        return self.duration_key((kind, segment))
 
     def part_duration(self, kind, segment, t0=0.0, t1=None):
-        self._need(kind, segment)
-        n = self.n_frames[(kind, segment)]
-        lo, hi = H.seconds_slice_frames(n, self.rate, t0, t1)
-        return ((hi - lo) / self.rate) or 1e-4
+        return self.part_duration_key((kind, segment), t0, t1)
+
+
+class ProsodySeam(BatchedMeasurements):
+    """The four measurement closures of ``AudioPipeline.measure_prosody_and_build_ssml`` (Code/audioPipeline.py:314-361)
+    with the reference's own signatures, keyed by WAV path, so that the reference's method can be rebound to the engine
+    without this package's ``AudioPipeline``:
+
+        seam = ProsodySeam(engine)
+        get_part_duration, get_median_pitch, get_lufs, get_duration = seam.closures()
+
+    Units and sentinels are the reference's: seconds in, Hz / LUFS / seconds out; ``0.0`` = no voiced frame (:335);
+    durations floored at ``1e-4`` (:322-323,:361); ``peak or 1.0`` (:349); a slice shorter than 0.4 s of the meter's rate,
+    or empty, falls back to the whole file (:345-358); an undecodable file raises ``CouldntDecodeError``.  ``meter`` is
+    anything with a ``rate`` attribute (``pyloudnorm.Meter``) or the rate itself.  ``prefetch`` batches queries known in
+    advance (every query of a voice follows from its TextGrids); anything else is computed on first use."""
+
+    def _key(self, wav_path):
+        key = str(wav_path)
+        self.add_file(key, key)
+        return key
+
+    def prefetch(self, pitch_queries=(), lufs_queries=()):
+        """pitch_queries: (path, t0, t1 | None); lufs_queries: (path, meter_rate, t0, t1 | None)."""
+        for path, t0, t1 in pitch_queries:
+            k = self._key(path)
+            if k in self.rate_of:
+                self.plan_pitch_key(k, t0, t1)
+        for path, meter, t0, t1 in lufs_queries:
+            k = self._key(path)
+            self.plan_lufs_key(k, t0, t1, getattr(meter, "rate", meter))
+        self.run()
+
+    def closures(self):
+        def get_part_duration(wav_path, t0=0.0, t1=None):
+            return self.part_duration_key(self._key(wav_path), t0, t1)
+
+        def get_median_pitch(wav_path, t0=0.0, t1=None):
+            return self.pitch_key(self._key(wav_path), t0, t1)
+
+        def get_lufs(wav_path, meter, t0=0.0, t1=None):
+            return self.lufs_key(self._key(wav_path), t0, t1, getattr(meter, "rate", meter))
+
+        def get_duration(wav_path):
+            return self.duration_key(self._key(wav_path))
+
+        return get_part_duration, get_median_pitch, get_lufs, get_duration
 
 
 class _Planner(MeasurementSource):
@@ -149,7 +265,7 @@ class _Planner(MeasurementSource):
         self.em.plan_pitch(segment, t0, t1); return 200.0
 
     def lufs(self, kind, segment, t0=0.0, t1=None):
-        self.em._need(kind, segment); self.em.plan_lufs(kind, segment, t0, t1); return -23.0
+        self.em._need((kind, segment)); self.em.plan_lufs(kind, segment, t0, t1); return -23.0
 
     def duration(self, kind, segment):
         return self.em.duration(kind, segment)
@@ -180,6 +296,14 @@ class AudioPipeline:
         self.device_index = int(str(self.whisper_device).split(":")[1]) if ":" in str(self.whisper_device) else 0
         self._engine, self._nlp = engine, nlp
         self.results_dir.mkdir(parents=True, exist_ok=True)
+        wanted = cfg.get("steps_to_run") or STEP_NAMES
+        unknown = [n for n in wanted if n not in STEP_NAMES]
+        if unknown:
+            raise ValueError(f"steps_to_run names unknown steps {unknown}; known: {STEP_NAMES}")
+        outside = [n for n in wanted if n not in ACCELERATED_STEPS]
+        if outside and cfg.get("strict_steps"):
+            raise NotImplementedError(f"steps {outside} are outside the accelerated hot path (SURVEY.md section 8): run them with the "
+                                      "reference implementation, or drop strict_steps to skip them")
 
     def _get_engine(self) -> ProsodyEngine:
         if self._engine is None:
@@ -209,21 +333,82 @@ class AudioPipeline:
         res.bdd_syntagme_for_synth.to_csv(self.bdd_syntagme_synth_csv, index=False)
         return res
 
-    # ------------------------------------------------------------------ step table
-    def _not_on_hot_path(self, step):
-        def f():
-            raise NotImplementedError(f'step "{step}" is outside the accelerated hot path (SURVEY.md section 8): '
-                                      "run it with the reference implementation")
-        return f
+    # ------------------------------------------------------------------ the Whisper steps
+    def _whisper_main(self, audio_folder, out_folder):
+        from .Aligners import use_whisper_timestamped as A
+        if self.cfg.get("whisper_dir"):
+            A.set_model_source(model_dir=str(self.cfg["whisper_dir"]))
+        if self._nlp is not None:
+            A.set_nlp(self._nlp)
+        if self._engine is not None:
+            from .engine import set_default_engine
+            set_default_engine(self._engine)
+        A.main(str(audio_folder), str(out_folder), whisper_model=self.whisper_model, device=self.whisper_device, logger=logging.getLogger())
 
+    def align_and_transcribe(self):
+        """Code/audioPipeline.py:179-241: fresh output folders, the aligner over ``<voice>/audio``, raw transcriptions from
+        the raw JSONs ("..." where a file produced none), cleaned transcriptions from the TextGrids."""
+        logging.info(">>> Align & Transcribe: WhisperTS")
+        from .Aligners.use_whisper_timestamped import remove_spurious_commas
+        from .Pipeline.utils import save_clean_transcriptions_from_textgrids
+        audio_folder = self.voice_dir / "audio"
+        tg_folder = self.voice_dir / "WhisperTS_textgrid_files"
+        txt_folder = self.voice_dir / "transcription"
+        txt_raw_folder = self.voice_dir / "transcription_raw"
+        raw_json_dir = Path(str(tg_folder) + "_raw_json")
+        for d in (tg_folder, txt_folder, self.voice_dir / "WhisperTS_textgrid_files_transcription", txt_raw_folder, raw_json_dir):
+            shutil.rmtree(d, ignore_errors=True)
+        for d in (tg_folder, txt_folder, txt_raw_folder, raw_json_dir):
+            d.mkdir(parents=True, exist_ok=True)
+        self._whisper_main(audio_folder, tg_folder)
+        for js in raw_json_dir.glob("*.raw.json"):
+            data = json.loads(js.read_text(encoding="utf-8"))
+            (txt_raw_folder / js.name.replace(".raw.json", ".txt")).write_text(" ".join(seg["text"] for seg in data["segments"]), encoding="utf-8")
+        for wav in Path(audio_folder).glob("*.wav"):
+            raw_txt = txt_raw_folder / f"{wav.stem}.txt"
+            if not raw_txt.exists():
+                raw_txt.write_text("...", encoding="utf-8")
+        save_clean_transcriptions_from_textgrids(tg_folder, txt_folder)
+        for txt in Path(txt_folder).glob("*.txt"):
+            txt.write_text(remove_spurious_commas(txt.read_text(encoding="utf-8")), encoding="utf-8")
+
+    def final_transcribe(self):
+        """Code/audioPipeline.py:856-892: the aligner over ``results/<voice>/OUT.wav``, results moved next to it."""
+        logging.info(">>> Final Transcribe: WhisperTS on OUT.wav")
+        from .Pipeline.utils import save_clean_transcriptions_from_textgrids
+        out_wav = self.results_dir / "OUT.wav"
+        if not out_wav.exists():
+            logging.error(f"No OUT.wav found at {out_wav}")
+            return
+        temp_dir = self.results_dir / "final_whisper"
+        tg_dir, txt_dir = temp_dir / "WhisperTS_textgrid_files", temp_dir / "transcription_final"
+        tg_dir.mkdir(parents=True, exist_ok=True); txt_dir.mkdir(parents=True, exist_ok=True)
+        self._whisper_main(out_wav.parent, tg_dir)
+        save_clean_transcriptions_from_textgrids(tg_dir, txt_dir)
+        for tg in tg_dir.glob("*.TextGrid"):
+            tg.rename(self.results_dir / tg.name)
+        for txt in txt_dir.glob("*.txt"):
+            txt.rename(self.results_dir / txt.name)
+        logging.info(f"Final transcription files saved in {self.results_dir}")
+
+    # ------------------------------------------------------------------ step table
     def run(self):
-        steps = {n: self._not_on_hot_path(n) for n in STEP_NAMES}
-        steps["Measure & Build SSML"] = self.measure_prosody_and_build_ssml
-        wanted = self.cfg.get("steps_to_run")
-        order = [n for n in STEP_NAMES if (not wanted or n in wanted)]
-        for n in order:
+        """Code/audioPipeline.py:1076-1103: the selected steps in the fixed order, ``sys.exit(1)`` when one raises, then
+        ``used_config.yaml`` in the results folder.  Steps outside the hot path are skipped with a warning."""
+        steps = {"Align+Transcribe": self.align_and_transcribe, "Measure & Build SSML": self.measure_prosody_and_build_ssml,
+                 "Final Transcribe": self.final_transcribe}
+        wanted = self.cfg.get("steps_to_run") or STEP_NAMES
+        for n in [n for n in STEP_NAMES if n in wanted]:
+            if n not in steps:
+                logging.warning(f'step "{n}" is outside the accelerated hot path (SURVEY.md section 8): skipped, run it with the reference implementation')
+                continue
             try:
                 steps[n]()
             except Exception:
-                logging.exception(f"Failed at step: {n}")
+                logging.exception(f"Failed step {n}")
                 sys.exit(1)
+        import yaml
+        config_path = self.results_dir / "used_config.yaml"
+        with open(config_path, "w", encoding="utf-8") as f:
+            yaml.dump(self.cfg, f, default_flow_style=False, allow_unicode=True)
+        logging.info(f"Config saved to {config_path}")

@@ -77,6 +77,7 @@ struct pce_ctx {
     int64_t lu_n_chunks = 0, lu_n_blocks = 0, lu_n_energy_work = 0;
     double lu_coef[13] = {0};
     int32_t lu_n = -1;
+    int32_t lu_meter_rate = 0;       // pce_lufs_set_meter_rate: 0 = the batch's own rate
     std::vector<int32_t> lu_host_status;
 
     // pitch

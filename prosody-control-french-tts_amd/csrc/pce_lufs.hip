@@ -286,7 +286,7 @@ static int lufs_plan(pce_ctx *c, const pce_slice *slices, int32_t n)
     std::vector<LuSlice> hs((size_t)(n > 0 ? n : 1));
     std::vector<LuChunk> chunks;
     std::vector<LuBlock> blocks;
-    const double rate = (double)c->rate;
+    const double rate = (double)(c->lu_meter_rate > 0 ? c->lu_meter_rate : c->rate);   // pyloudnorm.Meter(rate): the METER's rate, not necessarily the data's
     const double T_g = 0.400, step = 1.0 - 0.75;
     c->lu_host_status.assign((size_t)n, PCE_SLICE_OK);
     std::vector<int64_t> pts;
@@ -365,6 +365,13 @@ static int lufs_plan(pce_ctx *c, const pce_slice *slices, int32_t n)
 }
 
 extern "C" {
+
+int pce_lufs_set_meter_rate(pce_ctx *c, int32_t rate)
+{
+    if (!c || rate < 0) return PCE_E_INVALID;
+    if (c->lu_meter_rate != rate) { c->lu_meter_rate = rate; c->lu_cache.drop(); }
+    return PCE_OK;
+}
 
 int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
 {

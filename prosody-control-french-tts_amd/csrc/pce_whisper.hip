@@ -809,37 +809,65 @@ __global__ void k_cache_k(const bf16 *__restrict__ qk, int T_pad, const int *__r
     const int col = (int)(i % d); const int64_t r = i / d; const int t = (int)(r % T_pad), clip = (int)(r / T_pad);
     if (t < t_len[clip]) ck[((int64_t)clip * T_cap + t) * d + col] = qk[r * 2 * d + d + col];
 }
-__global__ void k_append_kv(const bf16 *__restrict__ qkv, int pos, int d, int T_cap, int sp, int n, bf16 *__restrict__ ck, bf16 *__restrict__ cvt)
+__global__ void k_append_kv(const bf16 *__restrict__ qkv, const int *__restrict__ pos_of, int d, int T_cap, int sp, int n, bf16 *__restrict__ ck,
+                            bf16 *__restrict__ cvt)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * d) return;
     const int clip = (int)(i / d), col = (int)(i - (int64_t)clip * d);
+    const int pos = pos_of[clip];
     ck[((int64_t)clip * T_cap + pos) * d + col] = qkv[(int64_t)clip * 3 * d + d + col];
     cvt[((int64_t)clip * d + col) * sp + pos] = qkv[(int64_t)clip * 3 * d + 2 * d + col];
 }
-__global__ void k_embed_one(const int *__restrict__ tok, const float *__restrict__ tok_emb, const float *__restrict__ pos_emb, int pos, int d, int n,
-                            float *__restrict__ out)
+__global__ void k_embed_one(const int *__restrict__ tok, const float *__restrict__ tok_emb, const float *__restrict__ pos_emb,
+                            const int *__restrict__ pos_of, int d, int n, float *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * d) return;
     const int clip = (int)(i / d), col = (int)(i - (int64_t)clip * d);
-    out[i] = tok_emb[(int64_t)tok[clip] * d + col] + pos_emb[(int64_t)pos * d + col];
+    out[i] = tok_emb[(int64_t)tok[clip] * d + col] + pos_emb[(int64_t)pos_of[clip] * d + col];
 }
 
 // openai-whisper decoding.py at temperature 0, one workgroup per sequence: SuppressBlank, SuppressTokens,
 // ApplyTimestampRules on the logits of the last position, then the GreedyDecoder's arg-max (first maximum) and its
 // "once end-of-text, always end-of-text" rule.  vmask: bit 0 = always suppressed (suppress list, no_timestamps),
 // bit 1 = suppressed at the first sampled position (blank, end of text).
-struct DecRules { int eot, ts_begin, n_vocab, ld, sample_begin, max_initial_ts; };
+struct DecRules { int eot, ts_begin, n_vocab, ld, sample_begin, max_initial_ts; float temperature; unsigned seed_lo, seed_hi; int probe; };
+// uniform in (0, 1) from (seed, clip, position, token): two rounds of the splitmix64 finaliser over the packed counter
+__device__ __forceinline__ float dec_uniform(unsigned seed_lo, unsigned seed_hi, int clip, int pos, int v)
+{
+    unsigned long long z = ((unsigned long long)seed_hi << 32 | seed_lo) + 0x9E3779B97F4A7C15ull * ((unsigned long long)(unsigned)clip << 40 ^ (unsigned long long)(unsigned)pos << 20 ^ (unsigned)v);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    return ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
 __global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits, const int *__restrict__ tokens, const int *__restrict__ t_len,
-                                                     int T_pad, const unsigned char *__restrict__ vmask, DecRules R, int *__restrict__ next,
-                                                     float *__restrict__ next_logprob)
+                                                     int T_pad, const unsigned char *__restrict__ vmask, DecRules R, const int *__restrict__ sample_begin_of,
+                                                     int *__restrict__ next, float *__restrict__ next_logprob, float *__restrict__ probe_prob)
 {
     __shared__ float r_f[2][4]; __shared__ int r_i[4]; __shared__ float s_bcast[2]; __shared__ int s_flags[4];
     const int clip = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int L = t_len[clip];
     const int *seq = tokens + (size_t)clip * T_pad;
     float *x = logits + (size_t)clip * R.ld;
+    if (sample_begin_of) R.sample_begin = sample_begin_of[clip];
+    if (R.probe >= 0 && probe_prob) {
+        // softmax of the unfiltered logits at one token (no_speech_prob when the prefix ends at <|startoftranscript|>)
+        float m = -__builtin_huge_valf();
+        for (int v = tid; v < R.n_vocab; v += 256) m = fmaxf(m, x[v]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) r_f[0][wv] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(r_f[0][0], r_f[0][1]), fmaxf(r_f[0][2], r_f[0][3]));
+        float se = 0.f;
+        for (int v = tid; v < R.n_vocab; v += 256) se += __expf(x[v] - m);
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+        if (lane == 0) r_f[1][wv] = se;
+        __syncthreads();
+        if (tid == 0) probe_prob[clip] = __expf(x[R.probe] - m) / ((r_f[1][0] + r_f[1][1]) + (r_f[1][2] + r_f[1][3]));
+        __syncthreads();
+    }
     if (tid == 0) {
         const int ns = L - R.sample_begin;                         // sampled tokens so far
         const bool last_ts = ns >= 1 && seq[L - 1] >= R.ts_begin;
@@ -890,10 +918,14 @@ __global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits
     }
     __syncthreads();
     const bool only_ts = s_bcast[0] != 0.f;
-    // pass 3: arg-max (first maximum)
+    // pass 3: arg-max (first maximum); at a temperature the arg-max of logits / temperature + Gumbel noise, which is one
+    // draw from softmax(logits / temperature) (Categorical(logits = logits / temperature).sample() of GreedyDecoder.update)
     float best = NEG; int bi = 0x7fffffff;
+    const bool sampling = R.temperature > 0.f;
+    const float inv_t = sampling ? 1.0f / R.temperature : 1.0f;
     for (int v = (only_ts ? R.ts_begin : 0) + tid; v < R.n_vocab; v += 256) {
-        const float a = x[v];
+        float a = x[v];
+        if (sampling && a > NEG) a = a * inv_t - __logf(-__logf(dec_uniform(R.seed_lo, R.seed_hi, clip, L, v)));
         if (a > best) { best = a; bi = v; }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -906,13 +938,13 @@ __global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits
         for (int u = 1; u < 4; u++) if (r_f[0][u] > best || (r_f[0][u] == best && r_i[u] < bi)) { best = r_f[0][u]; bi = r_i[u]; }
         if (bi == 0x7fffffff) bi = only_ts ? R.ts_begin : 0;       // every candidate is -inf: torch.argmax returns the first index
         next[clip] = done ? R.eot : bi;
-        s_bcast[1] = best;
+        s_bcast[1] = sampling ? x[bi] : best;                      // the choice's own (filtered, unscaled) logit
     }
     __syncthreads();
     // log-probability of the choice under the filtered distribution (GreedyDecoder.update adds it to sum_logprobs unless
     // the sequence had already ended): log_softmax over what is left after the filters
     {
-        const float top = s_bcast[1];
+        const float top = s_bcast[1];                              // (a sampled choice need not be the maximum: exp(x - top) may exceed 1, the sum stays exact enough in float)
         float se2 = 0.f;
         if (top > NEG)
             for (int v = (only_ts ? R.ts_begin : 0) + tid; v < R.n_vocab; v += 256) se2 += __expf(x[v] - top);
@@ -1144,7 +1176,8 @@ struct WhisperState {
     // self-attention K / V of the sequences decoded so far: K rows [layer][clip][T_cap][d], V^T [layer][clip][d][512]
     DevBuf g_sk, g_svt, g_c_resid, g_c_ln, g_c_qkv, g_c_attn, g_c_q, g_c_hidden, g_c_tab;
     std::vector<int> g_cache_tok;     // host copy of the cached prefixes [clip][T_cap]
-    int g_cache_len = -1, g_cache_n = -1;
+    int g_cache_len = -1, g_cache_n = -1;   // g_cache_len: < 0 = nothing cached (new encoded batch); per-sequence lengths in g_cache_lens
+    std::vector<int> g_cache_lens;
     struct DLayer { size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, lnx_w, lnx_b, xq_w, xq_b, xkv_w, xkv_b, xout_w, xout_b,
                     ln2_w, ln2_b, m1_w, m1_b, m2_w, m2_b; };
     std::vector<DLayer> dlayers;
@@ -1810,29 +1843,42 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
                                        const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, int32_t *next_tokens,
                                        float *next_logprobs)
 {
-    if (!c || !tokens || !token_offsets || !rules || !vocab_mask || !next_tokens) return PCE_E_INVALID;
+    pce_whisper_decode_opts o{};
+    o.sample_begin = nullptr; o.sample_begin_all = sample_begin; o.temperature = 0.f; o.probe_token = -1;
+    return pce_whisper_decode_step_ex(c, tokens, token_offsets, rules, vocab_mask, &o, next_tokens, next_logprobs, nullptr);
+}
+
+extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, const pce_whisper_decode_rules *rules,
+                                          const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts, int32_t *next_tokens,
+                                          float *next_logprobs, float *probe_prob)
+{
+    if (!c || !tokens || !token_offsets || !rules || !vocab_mask || !next_tokens || !opts) return PCE_E_INVALID;
+    const int32_t sample_begin = opts->sample_begin_all;
     WhisperState *w = ws_of(c);
     if (!w->dec_loaded) return pce_fail(c, PCE_E_STATE, "pce_whisper_decode_step before pce_whisper_decoder_load");
     if (w->n_clips_enc < 0) return pce_fail(c, PCE_E_STATE, "run pce_whisper_encode_run first");
     if (w->tdims.n_state != w->dims.n_state) return pce_fail(c, PCE_E_INVALID, "decoder and encoder widths differ");
     PCE_HIP(c, hipSetDevice(c->device));
     const int n = w->n_clips_enc, d = w->tdims.n_state, H = w->tdims.n_head, L = w->tdims.n_layer, V = w->tdims.n_vocab, SPD = 512;
-    if (rules->eot < 0 || rules->eot >= V || rules->timestamp_begin <= rules->eot || rules->timestamp_begin > V || sample_begin < 1)
+    if (rules->eot < 0 || rules->eot >= V || rules->timestamp_begin <= rules->eot || rules->timestamp_begin > V || (!opts->sample_begin && sample_begin < 1))
         return pce_fail(c, PCE_E_INVALID, "decoding rules: need 0 <= eot < timestamp_begin <= n_vocab, sample_begin >= 1");
+    if (!(opts->temperature >= 0.f) || opts->probe_token >= V) return pce_fail(c, PCE_E_INVALID, "decoding options: temperature >= 0, probe_token < n_vocab");
     if (n == 0) return PCE_OK;
     int T_max = 0;
     std::vector<int> t_len((size_t)n);
     for (int i = 0; i < n; i++) {
         const int T = token_offsets[i + 1] - token_offsets[i];
-        if (T < sample_begin || T > w->tdims.n_text_ctx) return pce_fail(c, PCE_E_INVALID, "clip %d: %d tokens (need %d..%d)", i, T, sample_begin, w->tdims.n_text_ctx);
+        const int sb = opts->sample_begin ? opts->sample_begin[i] : sample_begin;
+        if (sb < 1 || T < sb || T > w->tdims.n_text_ctx) return pce_fail(c, PCE_E_INVALID, "clip %d: %d tokens (need %d..%d)", i, T, sb, w->tdims.n_text_ctx);
         t_len[(size_t)i] = T; T_max = std::max(T_max, T);
     }
     const int T_pad = (int)div_up(T_max, 64) * 64;
     const int64_t Mt = (int64_t)n * T_pad, Ma = (int64_t)n * W_CTX;
     const int64_t Vp = div_up(V, 128) * 128;
-    std::vector<int> tab((size_t)4 * n), tok((size_t)Mt, 0);
+    std::vector<int> tab((size_t)5 * n), tok((size_t)Mt, 0);
     for (int i = 0; i < n; i++) {
         tab[(size_t)i] = i * T_pad; tab[(size_t)n + i] = t_len[(size_t)i]; tab[(size_t)2 * n + i] = i * W_CTX; tab[(size_t)3 * n + i] = W_CTX;
+        tab[(size_t)4 * n + i] = opts->sample_begin ? opts->sample_begin[i] : sample_begin;
         for (int t = 0; t < t_len[(size_t)i]; t++) {
             const int v = tokens[token_offsets[i] + t];
             if (v < 0 || v >= V) return pce_fail(c, PCE_E_INVALID, "token %d out of the vocabulary", v);
@@ -1851,7 +1897,7 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     PCE_HIP(c, w->g_lastln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
     PCE_HIP(c, w->g_logits.reserve(sizeof(float) * (size_t)n * (size_t)Vp));
     PCE_HIP(c, w->g_mask.reserve((size_t)V + 64));
-    PCE_HIP(c, w->g_next.reserve((sizeof(int) + sizeof(float)) * (size_t)n));
+    PCE_HIP(c, w->g_next.reserve((sizeof(int) + 2 * sizeof(float)) * (size_t)n));
     PCE_HIP(c, hipMemcpyAsync(w->d_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipMemcpyAsync(w->d_tokens.p, tok.data(), sizeof(int) * tok.size(), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipMemcpyAsync(w->g_mask.p, vocab_mask, (size_t)V, hipMemcpyHostToDevice, c->stream));
@@ -1884,22 +1930,24 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
         PCE_HIP(c, w->g_svt.reserve(sizeof(bf16) * svt_l * (size_t)L + 4096));
         PCE_HIP(c, hipMemsetAsync(w->g_sk.p, 0, sizeof(bf16) * sk_l * (size_t)L, c->stream));
         PCE_HIP(c, hipMemsetAsync(w->g_svt.p, 0, sizeof(bf16) * svt_l * (size_t)L, c->stream));
-        w->g_cache_n = n; w->g_cache_len = -1; w->g_cache_tok.assign((size_t)n * T_cap, 0);
+        w->g_cache_n = n; w->g_cache_len = -1; w->g_cache_tok.assign((size_t)n * T_cap, 0); w->g_cache_lens.assign((size_t)n, -1);
     }
-    bool uniform = true;
-    for (int i = 1; i < n; i++) uniform = uniform && t_len[(size_t)i] == t_len[0];
-    const int Lc = t_len[0];
-    bool incremental = uniform && w->g_cache_len == Lc - 1 && Lc >= 2 && !getenv("PCE_DECODE_NO_CACHE");
-    for (int i = 0; incremental && i < n; i++)
-        incremental = memcmp(&w->g_cache_tok[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)(Lc - 1)) == 0;
+    // incremental: every sequence extends what the cache holds for it by exactly one token (lengths may differ between sequences)
+    static const bool no_cache = getenv("PCE_DECODE_NO_CACHE") != nullptr;
+    bool incremental = w->g_cache_len >= 0 && !no_cache;
+    for (int i = 0; incremental && i < n; i++) {
+        const int Li = t_len[(size_t)i];
+        incremental = Li >= 2 && w->g_cache_lens[(size_t)i] == Li - 1 &&
+                      memcmp(&w->g_cache_tok[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)(Li - 1)) == 0;
+    }
     const bf16 *last_ln = nullptr;                                // [n][d] bf16: the final LayerNorm of the last position
     if (incremental) {
         // ---- one new position per sequence: every GEMM has M = clips rows, the attention one query per (clip, head)
-        const int pos = Lc - 1;
-        std::vector<int> ct((size_t)7 * n);                     // new token | q_row0 | q_len | k_row0 | k_len | a_row0 | a_len
+        std::vector<int> ct((size_t)8 * n);                     // new token | q_row0 | q_len | k_row0 | k_len | a_row0 | a_len | position
         for (int i = 0; i < n; i++) {
-            ct[(size_t)i] = tokens[token_offsets[i] + pos]; ct[(size_t)n + i] = i; ct[(size_t)2 * n + i] = 1; ct[(size_t)3 * n + i] = i * T_cap;
-            ct[(size_t)4 * n + i] = Lc; ct[(size_t)5 * n + i] = i * W_CTX; ct[(size_t)6 * n + i] = W_CTX;
+            const int pos_i = t_len[(size_t)i] - 1;
+            ct[(size_t)i] = tokens[token_offsets[i] + pos_i]; ct[(size_t)n + i] = i; ct[(size_t)2 * n + i] = 1; ct[(size_t)3 * n + i] = i * T_cap;
+            ct[(size_t)4 * n + i] = pos_i + 1; ct[(size_t)5 * n + i] = i * W_CTX; ct[(size_t)6 * n + i] = W_CTX; ct[(size_t)7 * n + i] = pos_i;
         }
         PCE_HIP(c, w->g_c_tab.reserve(sizeof(int) * ct.size()));
         PCE_HIP(c, w->g_c_resid.reserve(sizeof(float) * (size_t)n * d));
@@ -1910,9 +1958,10 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
         PCE_HIP(c, w->g_c_hidden.reserve(sizeof(bf16) * (size_t)(n + 128) * 4 * d + 4096));
         PCE_HIP(c, hipMemcpyAsync(w->g_c_tab.p, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice, c->stream));
         PCE_HIP(c, hipStreamSynchronize(c->stream));
-        const int *CT = w->g_c_tab.as<int>(), *Q0 = CT + n, *QL = CT + 2 * n, *K0 = CT + 3 * n, *KL = CT + 4 * n, *X0 = CT + 5 * n, *XL = CT + 6 * n;
+        const int *CT = w->g_c_tab.as<int>(), *Q0 = CT + n, *QL = CT + 2 * n, *K0 = CT + 3 * n, *KL = CT + 4 * n, *X0 = CT + 5 * n, *XL = CT + 6 * n,
+                  *POS = CT + 7 * n;
         hipLaunchKernelGGL(k_embed_one, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, CT, w->d_tok_emb.as<float>(),
-                           w->d_pos_emb.as<float>(), pos, d, n, w->g_c_resid.as<float>());
+                           w->d_pos_emb.as<float>(), POS, d, n, w->g_c_resid.as<float>());
         auto cattn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp, const int *k0, const int *kl) {
             AttnArgs a{};
             a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
@@ -1927,7 +1976,7 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
             const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
             cln(ly.ln1_w, ly.ln1_b);
             launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, n, 3 * d, d, Wf + ly.qkv_b, w->g_c_qkv.as<bf16>(), 3 * d, 0, 1);
-            hipLaunchKernelGGL(k_append_kv, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, w->g_c_qkv.as<bf16>(), pos, d, T_cap, SPD, n,
+            hipLaunchKernelGGL(k_append_kv, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, w->g_c_qkv.as<bf16>(), POS, d, T_cap, SPD, n,
                                w->g_sk.as<bf16>() + sk_l * (size_t)l, w->g_svt.as<bf16>() + svt_l * (size_t)l);
             cattn(w->g_c_qkv.as<bf16>(), 3 * d, w->g_sk.as<bf16>() + sk_l * (size_t)l, d, w->g_svt.as<bf16>() + svt_l * (size_t)l, (int64_t)d * SPD, SPD, K0, KL);
             launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.out_w, n, d, d, Wf + ly.out_b, w->g_c_resid.as<float>(), d, 0, 1);
@@ -1982,19 +2031,24 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
                        (int64_t)n, d, w->g_lastln.as<bf16>());
     last_ln = w->g_lastln.as<bf16>();
     }
-    // the cache now holds every position of these prefixes (when they all have one length)
-    if (uniform) {
-        for (int i = 0; i < n; i++) memcpy(&w->g_cache_tok[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)Lc);
-        w->g_cache_len = Lc;
-    } else w->g_cache_len = -1;
+    // the cache now holds every position of these prefixes
+    for (int i = 0; i < n; i++) {
+        memcpy(&w->g_cache_tok[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)t_len[(size_t)i]);
+        w->g_cache_lens[(size_t)i] = t_len[(size_t)i];
+    }
+    w->g_cache_len = 0;
     PCE_HIP(c, hipMemsetAsync(w->g_logits.p, 0, sizeof(float) * (size_t)n * (size_t)Vp, c->stream));
     launch_gemm<EPI_RESID_F32>(c, last_ln, d, 0, w->g_emb_bf16.as<bf16>(), n, (int)Vp, d, nullptr, w->g_logits.as<float>(), Vp, 0, 1);
-    DecRules R{rules->eot, rules->timestamp_begin, V, (int)Vp, sample_begin, rules->max_initial_timestamp_index};
+    DecRules R{rules->eot, rules->timestamp_begin, V, (int)Vp, sample_begin, rules->max_initial_timestamp_index, opts->temperature, opts->seed_lo,
+               opts->seed_hi, probe_prob ? opts->probe_token : -1};
     hipLaunchKernelGGL(k_decode_rules, dim3((unsigned)n), dim3(256), 0, c->stream, w->g_logits.as<float>(), w->d_tokens.as<int>(), TL, T_pad,
-                       w->g_mask.as<unsigned char>(), R, w->g_next.as<int>(), reinterpret_cast<float *>(w->g_next.as<int>() + n));
+                       w->g_mask.as<unsigned char>(), R, T0 + 4 * n, w->g_next.as<int>(), reinterpret_cast<float *>(w->g_next.as<int>() + n),
+                       reinterpret_cast<float *>(w->g_next.as<int>() + 2 * n));
     PCE_HIP(c, hipGetLastError());
     PCE_HIP(c, hipMemcpyAsync(next_tokens, w->g_next.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (next_logprobs) PCE_HIP(c, hipMemcpyAsync(next_logprobs, w->g_next.as<int>() + n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (probe_prob && opts->probe_token >= 0)
+        PCE_HIP(c, hipMemcpyAsync(probe_prob, w->g_next.as<int>() + 2 * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     return PCE_OK;
 }

@@ -74,6 +74,11 @@ class WhisperDecodeRules(C.Structure):
     _fields_ = [("eot", C.c_int32), ("timestamp_begin", C.c_int32), ("max_initial_timestamp_index", C.c_int32), ("reserved", C.c_int32)]
 
 
+class WhisperDecodeOpts(C.Structure):
+    _fields_ = [("sample_begin", C.c_void_p), ("sample_begin_all", C.c_int32), ("temperature", C.c_float), ("seed_lo", C.c_uint32),
+                ("seed_hi", C.c_uint32), ("probe_token", C.c_int32), ("reserved", C.c_int32)]
+
+
 class BertDims(C.Structure):
     _fields_ = [("n_vocab", C.c_int32), ("n_pos", C.c_int32), ("n_type", C.c_int32), ("n_state", C.c_int32), ("n_head", C.c_int32),
                 ("n_layer", C.c_int32), ("n_labels", C.c_int32)]
@@ -96,12 +101,12 @@ KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
            "pce_upload_pcm_s16", "pce_bind_pcm_s16_device", "pce_num_clips",
-           "pce_energy_run", "pce_energy_fetch", "pce_lufs_run", "pce_lufs_fetch",
+           "pce_energy_run", "pce_energy_fetch", "pce_lufs_set_meter_rate", "pce_lufs_run", "pce_lufs_fetch",
            "pce_frame_energy_run", "pce_frame_energy_shape", "pce_frame_energy_fetch", "pce_pyin_run", "pce_pyin_shape", "pce_pyin_fetch",
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step",
+           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
@@ -124,6 +129,7 @@ def load_library() -> C.CDLL:
     lib.pce_num_clips.argtypes = [vp]
     lib.pce_energy_run.argtypes = [vp, vp, i32, i32]
     lib.pce_energy_fetch.argtypes = [vp, vp]
+    lib.pce_lufs_set_meter_rate.argtypes = [vp, i32]
     lib.pce_lufs_run.argtypes = [vp, vp, i32]
     lib.pce_frame_energy_run.argtypes = [vp, i32, i32, i32]
     lib.pce_pyin_run.argtypes = [vp, vp, vp, i64]
@@ -149,6 +155,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_align_run.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_float]
     lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_whisper_decode_step.argtypes = [vp, vp, vp, i32, C.POINTER(WhisperDecodeRules), vp, vp, vp]
+    lib.pce_whisper_decode_step_ex.argtypes = [vp, vp, vp, C.POINTER(WhisperDecodeRules), vp, C.POINTER(WhisperDecodeOpts), vp, vp, vp]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
@@ -270,6 +277,10 @@ class ProsodyEngine:
     def energy(self, slices, loud_threshold: int = 500) -> np.ndarray:
         self.energy_run(slices, loud_threshold)
         return self.energy_fetch()
+
+    def lufs_set_meter_rate(self, rate: int = 0):
+        """``pyln.Meter(rate)`` of the following ``lufs`` calls (0: the batch's own rate)."""
+        self._check(self._lib.pce_lufs_set_meter_rate(self._ctx, int(rate)))
 
     def lufs_run(self, slices):
         s = self._slices(slices); self._lu_n = len(s)
@@ -473,6 +484,28 @@ class ProsodyEngine:
                                                       vm.ctypes.data, nxt.ctypes.data, lp.ctypes.data))
         self.last_decode_logprobs = lp
         return nxt
+
+    def whisper_decode_step_ex(self, token_lists, sample_begin, eot: int, timestamp_begin: int, vocab_mask, max_initial_timestamp_index=None,
+                               temperature: float = 0.0, seed: int = 0, probe_token: int = -1):
+        """``whisper_decode_step`` with a prompt length per sequence (``sample_begin``: int or one per clip), sampling at a
+        temperature (one draw from softmax(filtered logits / temperature), reproducible for a given ``seed``) and an
+        optional probe of the unfiltered distribution at one token (``probe_token``: no_speech_prob when the prefixes end at
+        <|startoftranscript|>).  -> (next ids int32 [clips], log-probabilities float32 [clips], probe float32 [clips] | None)."""
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32) for t in token_lists]), dtype=np.int32)
+        off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
+        rules = WhisperDecodeRules(int(eot), int(timestamp_begin), -1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index), 0)
+        vm = np.ascontiguousarray(vocab_mask, dtype=np.uint8)
+        n = len(token_lists)
+        sb = None if np.isscalar(sample_begin) else np.ascontiguousarray(sample_begin, dtype=np.int32)
+        if sb is not None and sb.shape != (n,):
+            raise ValueError("sample_begin: one prompt length per sequence")
+        opts = WhisperDecodeOpts(sb.ctypes.data if sb is not None else None, int(sample_begin) if sb is None else 0, float(temperature),
+                                 int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF, int(probe_token), 0)
+        nxt = np.zeros(n, dtype=np.int32); lp = np.zeros(n, dtype=np.float32)
+        pr = np.zeros(n, dtype=np.float32) if probe_token >= 0 else None
+        self._check(self._lib.pce_whisper_decode_step_ex(self._ctx, toks.ctypes.data, off.ctypes.data, C.byref(rules), vm.ctypes.data, C.byref(opts),
+                                                         nxt.ctypes.data, lp.ctypes.data, pr.ctypes.data if pr is not None else None))
+        return nxt, lp, pr
 
     # ---------------------------------------------------------------- probabilistic YIN (viewers)
     def pyin_run(self, plan, tables):

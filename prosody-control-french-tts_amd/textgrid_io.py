@@ -9,18 +9,34 @@ from __future__ import annotations
 
 import re
 from dataclasses import dataclass, field
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 
 @dataclass
 class IntervalTier:
+    """``textgrid.IntervalTier(name, minTime=0.0, maxTime=None)``: intervals kept sorted, no overlaps."""
     name: str = ""
     intervals: List[Tuple[float, float, str]] = field(default_factory=list)
+    tier_min: float = 0.0
+    tier_max: Optional[float] = None
 
-    def add(self, t_min: float, t_max: float, mark: str):
+    def add(self, t_min, t_max, mark: str):
+        """``IntervalTier.add``: ValueError for an empty / inverted interval (``textgrid.Interval``), one that starts
+        before the tier or ends after it, and one that overlaps an interval already there (the sorted insertion compares
+        intervals, and comparing overlapping intervals raises) -- the errors that make the reference give a file up."""
         if t_min >= t_max:
-            raise ValueError(f"interval [{t_min}, {t_max}] is empty or inverted")      # textgrid.Interval raises too
-        self.intervals.append((float(t_min), float(t_max), mark))
+            raise ValueError(t_min, t_max)
+        if t_min < self.tier_min:
+            raise ValueError(self.tier_min)
+        if self.tier_max and t_max > self.tier_max:
+            raise ValueError(self.tier_max)
+        for a, b, _ in self.intervals:
+            if a < t_max and t_min < b:
+                raise ValueError((a, b), (t_min, t_max))
+        k = 0
+        while k < len(self.intervals) and self.intervals[k][0] < t_min:
+            k += 1
+        self.intervals.insert(k, (t_min, t_max, mark))
 
     @property
     def min_time(self):
@@ -83,7 +99,7 @@ def read_textgrid(path) -> TextGrid:
     for _ in range(n_tiers):
         cls = take("str"); name = take("str")
         t0 = take("num"); t1 = take("num"); n = int(take("num"))
-        tier = IntervalTier(name)
+        tier = IntervalTier(name, tier_min=t0, tier_max=t1)
         for _ in range(n):
             if cls == "IntervalTier":
                 a = take("num"); b = take("num"); m = take("str")
@@ -99,33 +115,47 @@ def _q(s: str) -> str:
     return '"' + s.replace('"', '""') + '"'
 
 
-def write_textgrid(tg: TextGrid, path):
-    """Long text format, gaps between intervals filled with empty marks like textgrid's writer."""
-    max_t = tg.max_time or max((t.max_time for t in tg.tiers), default=0.0)
-    min_t = tg.min_time
-    out = ['File type = "ooTextFile"', 'Object class = "TextGrid"', "", f"xmin = {min_t} ", f"xmax = {max_t} ",
-           "tiers? <exists> ", f"size = {len(tg.tiers)} ", "item []: "]
+def _gaps_filled(tier: IntervalTier, null: str = ""):
+    """``IntervalTier._fillInTheGaps``: empty-mark intervals between the tier's start, the intervals and the TIER's own
+    end (a tier created without ``maxTime`` gets no trailing filler)."""
+    out, prev = [], tier.tier_min
+    for a, b, m in tier.intervals:
+        if prev < a:
+            out.append((prev, a, null))
+        out.append((a, b, m)); prev = b
+    if tier.tier_max is not None and prev < tier.tier_max:
+        out.append((prev, tier.tier_max, null))
+    return out
+
+
+def format_textgrid(tg: TextGrid) -> str:
+    """The long text format exactly as ``textgrid==1.6.1``'s ``TextGrid.write`` prints it (tab indentation, numbers through
+    ``str``, quotes doubled): what the reference's ``tg.write(path)`` leaves on disk
+    (Code/Aligners/use_whisper_timestamped.py:612,638,656,692)."""
+    max_t = tg.max_time
+    if not max_t:
+        max_t = max([(t.tier_max if t.tier_max else t.max_time) for t in tg.tiers])
+    out = ['File type = "ooTextFile"', 'Object class = "TextGrid"\n', f"xmin = {tg.min_time}", f"xmax = {max_t}", "tiers? <exists>",
+           f"size = {len(tg.tiers)}", "item []:"]
     for ti, tier in enumerate(tg.tiers, 1):
-        ivs = []
-        cur = min_t
-        for a, b, m in tier.intervals:
-            if a > cur:
-                ivs.append((cur, a, ""))
-            ivs.append((a, b, m)); cur = b
-        if cur < max_t:
-            ivs.append((cur, max_t, ""))
-        out += [f"    item [{ti}]:", '        class = "IntervalTier" ', f"        name = {_q(tier.name)} ",
-                f"        xmin = {min_t} ", f"        xmax = {max_t} ", f"        intervals: size = {len(ivs)} "]
+        ivs = _gaps_filled(tier)
+        out += [f"\titem [{ti}]:", '\t\tclass = "IntervalTier"', f'\t\tname = "{tier.name}"', f"\t\txmin = {tier.tier_min}", f"\t\txmax = {max_t}",
+                f"\t\tintervals: size = {len(ivs)}"]
         for k, (a, b, m) in enumerate(ivs, 1):
-            out += [f"        intervals [{k}]:", f"            xmin = {a} ", f"            xmax = {b} ", f"            text = {_q(m)} "]
+            out += [f"\t\t\tintervals [{k}]:", f"\t\t\t\txmin = {a}", f"\t\t\t\txmax = {b}", f'\t\t\t\ttext = {_q(m)}']
+    return "\n".join(out) + "\n"
+
+
+def write_textgrid(tg: TextGrid, path):
     with open(path, "w", encoding="utf-8") as f:
-        f.write("\n".join(out) + "\n")
+        f.write(format_textgrid(tg))
 
 
 def words_to_textgrid(result: dict) -> TextGrid:
     """``json_to_textgrid`` (Code/Aligners/use_whisper_timestamped.py:330-395) on an in-memory
     transcription dict: one "words" tier, " " fillers for gaps, ``start >= end`` repaired by
-    +10 ms, "[*]" -> " ", a single "..." interval when there is no word."""
+    +10 ms, "[*]" -> " ", a single "..." interval when there is no word; ``maxTime`` of the grid = end of the last word.
+    Raises ValueError where ``textgrid`` would (overlapping words)."""
     tier = IntervalTier("words")
     cur, total = 0.0, 0
     for seg in result["segments"]:
