@@ -288,7 +288,7 @@ typedef struct pce_whisper_decode_opts {
     float temperature;             /* 0: arg-max (first maximum) */
     uint32_t seed_lo, seed_hi;
     int32_t probe_token;           /* < 0: no probe */
-    int32_t reserved;
+    int32_t flags;                 /* bit 0: do not use the self-attention K / V cache (re-run the decoder over the whole prefix: the check of the cache) */
 } pce_whisper_decode_opts;
 int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets /* [clips + 1] */,
                                const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts,

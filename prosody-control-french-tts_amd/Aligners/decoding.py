@@ -47,7 +47,7 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
 
 
 def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, sample_len: int, temperature: float = 0.0, seed: int = 0,
-                 active=None):
+                 active=None, no_cache: bool = False):
     """``greedy_decode`` with one prompt per clip (``condition_on_previous_text`` gives every recording its own) and an
     optional temperature (GreedyDecoder at temperature t: one sample per step from softmax(filtered logits / t)).
     ``active[i]`` False: the clip is left alone (it reads as ended from the first step on).
@@ -61,7 +61,7 @@ def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, samp
     lps = [[] for _ in range(n)]
     for _ in range(sample_len):
         nxt, lp, _ = engine.whisper_decode_step_ex(seqs, begins, eot, rules["timestamp_begin"], mask, rules.get("max_initial_timestamp_index"),
-                                                   temperature=temperature, seed=seed)
+                                                   temperature=temperature, seed=seed, no_cache=no_cache)
         for i in range(n):
             ended = seqs[i][-1] == eot and len(seqs[i]) > begins[i]
             seqs[i].append(int(nxt[i]))

@@ -1933,8 +1933,7 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
         w->g_cache_n = n; w->g_cache_len = -1; w->g_cache_tok.assign((size_t)n * T_cap, 0); w->g_cache_lens.assign((size_t)n, -1);
     }
     // incremental: every sequence extends what the cache holds for it by exactly one token (lengths may differ between sequences)
-    static const bool no_cache = getenv("PCE_DECODE_NO_CACHE") != nullptr;
-    bool incremental = w->g_cache_len >= 0 && !no_cache;
+    bool incremental = w->g_cache_len >= 0 && !(opts->flags & 1);
     for (int i = 0; incremental && i < n; i++) {
         const int Li = t_len[(size_t)i];
         incremental = Li >= 2 && w->g_cache_lens[(size_t)i] == Li - 1 &&

@@ -76,7 +76,7 @@ class WhisperDecodeRules(C.Structure):
 
 class WhisperDecodeOpts(C.Structure):
     _fields_ = [("sample_begin", C.c_void_p), ("sample_begin_all", C.c_int32), ("temperature", C.c_float), ("seed_lo", C.c_uint32),
-                ("seed_hi", C.c_uint32), ("probe_token", C.c_int32), ("reserved", C.c_int32)]
+                ("seed_hi", C.c_uint32), ("probe_token", C.c_int32), ("flags", C.c_int32)]
 
 
 class BertDims(C.Structure):
@@ -486,7 +486,7 @@ class ProsodyEngine:
         return nxt
 
     def whisper_decode_step_ex(self, token_lists, sample_begin, eot: int, timestamp_begin: int, vocab_mask, max_initial_timestamp_index=None,
-                               temperature: float = 0.0, seed: int = 0, probe_token: int = -1):
+                               temperature: float = 0.0, seed: int = 0, probe_token: int = -1, no_cache: bool = False):
         """``whisper_decode_step`` with a prompt length per sequence (``sample_begin``: int or one per clip), sampling at a
         temperature (one draw from softmax(filtered logits / temperature), reproducible for a given ``seed``) and an
         optional probe of the unfiltered distribution at one token (``probe_token``: no_speech_prob when the prefixes end at
@@ -500,7 +500,7 @@ class ProsodyEngine:
         if sb is not None and sb.shape != (n,):
             raise ValueError("sample_begin: one prompt length per sequence")
         opts = WhisperDecodeOpts(sb.ctypes.data if sb is not None else None, int(sample_begin) if sb is None else 0, float(temperature),
-                                 int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF, int(probe_token), 0)
+                                 int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF, int(probe_token), 1 if no_cache else 0)
         nxt = np.zeros(n, dtype=np.int32); lp = np.zeros(n, dtype=np.float32)
         pr = np.zeros(n, dtype=np.float32) if probe_token >= 0 else None
         self._check(self._lib.pce_whisper_decode_step_ex(self._ctx, toks.ctypes.data, off.ctypes.data, C.byref(rules), vm.ctypes.data, C.byref(opts),
