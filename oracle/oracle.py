@@ -329,8 +329,11 @@ def lufs_numpy(samples: np.ndarray, rate) -> float:
         return float(-0.691 + 10.0 * np.log10(zavg))
 
 
-def get_lufs(pcm: np.ndarray, rate, t0=0.0, t1=None, impl=lufs_c) -> float:
-    """``get_lufs`` closure, Code/audioPipeline.py:338-358 (meter rate == file rate)."""
+def get_lufs(pcm: np.ndarray, rate, t0=0.0, t1=None, impl=lufs_c, meter_rate=None) -> float:
+    """``get_lufs`` closure, Code/audioPipeline.py:338-358.  ``rate``: the file's own frame rate (pydub's slicing);
+    ``meter_rate``: the rate of the ``pyln.Meter`` handed in (:372,:493 build it from the NATURAL recording, also for the raw
+    synthesis whose rate differs) -- pyloudnorm never sees the data's rate, only the meter's; default: the file's."""
+    meter_rate = rate if meter_rate is None else meter_rate
     if t1 is not None:
         s = pydub_samples(pcm, rate, int(t0 * 1000), int(t1 * 1000))
     else:
@@ -338,9 +341,9 @@ def get_lufs(pcm: np.ndarray, rate, t0=0.0, t1=None, impl=lufs_c) -> float:
     if s.size == 0:
         s = pcm
     try:
-        return impl(s.astype(float), rate)
+        return impl(s.astype(float), meter_rate)
     except ValueError:
-        return impl(pcm.astype(float), rate)
+        return impl(pcm.astype(float), meter_rate)
 
 
 def part_duration(n_frames, rate, t0=0.0, t1=None) -> float:

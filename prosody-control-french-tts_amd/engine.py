@@ -559,6 +559,14 @@ class ProsodyEngine:
                                            int(match), int(mismatch), int(gap), oi.ctypes.data, oj.ctypes.data, ol.ctypes.data))
         return [(oi[oo[k]:oo[k] + ol[k]].copy(), oj[oo[k]:oo[k] + ol[k]].copy()) for k in range(len(pairs))]
 
+    # ---------------------------------------------------------------- the reference's measurement closures
+    def closures(self):
+        """``(get_part_duration, get_median_pitch, get_lufs, get_duration)`` with the signatures of the closures inside
+        ``AudioPipeline.measure_prosody_and_build_ssml`` (Code/audioPipeline.py:314-361), answered by this engine
+        (``audio_pipeline.ProsodySeam``: path-keyed, batched when the queries are announced with ``prefetch``)."""
+        from .audio_pipeline import ProsodySeam
+        return ProsodySeam(self).closures()
+
     # ---------------------------------------------------------------- measurement
     def profile_enable(self, on=True):
         self._check(self._lib.pce_profile_enable(self._ctx, 1 if on else 0))

@@ -187,3 +187,17 @@ def test_pitch_other_rates_match_oracle(engine, rate, floor):
         assert len(f0) == len(want["f0"]) and np.array_equal(f0 > 0, v) and v.sum() > 10
         assert np.max(np.abs(f0[v] - want["f0"][v]) / want["f0"][v]) <= 1e-6
         assert np.max(np.abs(sg[v] - want["strength"][v])) <= 1e-6
+
+
+@pytest.mark.parametrize("rate", [48000, 16000])
+def test_lufs_ebu_tech_3341_cases_on_the_gpu(engine, rate):
+    """The five EBU Tech 3341 integrated-loudness cases (tests/test_oracle_kat.py: schedule, published targets and their
+    translation to this mono, peak-normalised path) through pce_lufs_run: within the document's +-0.1 LU of the target and
+    within 1e-6 LU of the oracle."""
+    from tests.test_oracle_kat import EBU_3341, ebu_3341_signal
+    sigs = [ebu_3341_signal(c, rate) for c in sorted(EBU_3341)]
+    engine.upload([s for s, _ in sigs], rate)
+    vals, st = engine.lufs(engine.whole_clip_slices())
+    for (x, want), v, code in zip(sigs, vals, st):
+        assert code == 0 and abs(v - want) <= 0.1, (rate, v, want)
+        assert abs(v - O.lufs_c(x.astype(np.float64), rate)) <= 1e-6

@@ -228,3 +228,135 @@ def test_resampler_and_whisper_front_end_on_demo_audio(engine, excerpts):
     f = res["f0"][res["frame_offsets"][0]:res["frame_offsets"][1]]
     want = O.pitch_ac(got[0] / 32768.0, 1 / 16000, 0.5 / 16000, O.praat_params(150.0, 600.0))["f0"]
     assert np.array_equal(f > 0, want > 0) and np.max(np.abs(f[want > 0] - want[want > 0]) / want[want > 0]) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A voice as the reference's data really looks: 44.1 kHz recordings, 16 kHz raw synthesis (Azure's default RIFF output)
+# ---------------------------------------------------------------------------------------------------------------
+def _voice_with_mixed_rates(tmp_path, excerpts, n_seg=5):
+    rate, clips = excerpts
+    rng = np.random.default_rng(23)
+    voice = tmp_path / "Data" / "v1"
+    (voice / "audio").mkdir(parents=True); (voice / "WhisperTS_textgrid_files").mkdir()
+    raw = tmp_path / "Data" / "v1_raw" / "audio"; raw.mkdir(parents=True)
+    words = ["Bonjour", "le", "monde,", "voilà", "une", "phrase.", "Très", "longue", "ici?", "oui", "de", "la", "mer!"]
+    pcm, rates, segs = {}, {}, []
+    for k, name in enumerate(sorted(clips)[:n_seg]):
+        seg = f"segment_ph{k + 1}"
+        nat = clips[name]
+        syn = O.resample_int16(np.clip(np.roll(nat, 500).astype(np.int32) * 2 // 3, -32768, 32767).astype(np.int16), rate, 16000)
+        syn = syn[: int(len(syn) * rng.uniform(0.85, 1.0))]
+        _write_wav(voice / "audio" / f"{seg}.wav", nat, rate); _write_wav(raw / f"{seg}.wav", syn, 16000)
+        pcm[("nat", seg)], pcm[("syn", seg)] = nat, syn
+        rates[("nat", seg)], rates[("syn", seg)] = rate, 16000
+        t, ivs = 0.0, []
+        while t < 1.05:
+            d = float(np.round(rng.uniform(0.09, 0.3), 3)); ivs.append((t, t + d, str(rng.choice(words)))); t += d
+            if rng.random() < 0.4:
+                d = float(np.round(rng.choice([0.06, 0.16, 0.25]), 3)); ivs.append((t, t + d, " ")); t += d
+        TG.write_textgrid(TG.TextGrid([TG.IntervalTier("words", ivs)], 0.0, t), voice / "WhisperTS_textgrid_files" / f"{seg}.TextGrid")
+        segs.append(T.SegmentInput(seg, TG.read_textgrid(voice / "WhisperTS_textgrid_files" / f"{seg}.TextGrid").tiers[0].intervals))
+    return voice, raw, pcm, rates, segs
+
+
+class MixedRateOracle(T.MeasurementSource):
+    """The reference closures on the CPU oracle with the reference's meters: ONE meter at the first natural file's rate for
+    the segment-level numbers (Code/audioPipeline.py:372), one at the segment's natural rate for its syntagmes (:493)."""
+
+    def __init__(self, pcm, rates, first_nat_rate):
+        self.pcm, self.rates, self.first = pcm, rates, first_nat_rate
+
+    def median_pitch(self, segment, t0=0.0, t1=None):
+        return O.median_pitch(self.pcm[("nat", segment)], self.rates[("nat", segment)], t0, t1)
+
+    def lufs(self, kind, segment, t0=0.0, t1=None):
+        meter = self.first if t1 is None else self.rates[("nat", segment)]
+        return O.get_lufs(self.pcm[(kind, segment)], self.rates[(kind, segment)], t0, t1, impl=O.lufs_numpy, meter_rate=meter)
+
+    def duration(self, kind, segment):
+        return O.part_duration(len(self.pcm[(kind, segment)]), self.rates[(kind, segment)])
+
+    def part_duration(self, kind, segment, t0=0.0, t1=None):
+        return O.part_duration(len(self.pcm[(kind, segment)]), self.rates[(kind, segment)], t0, t1)
+
+
+CFG = {"data_dir": "Data", "out_dir": "Out", "azure_voice_name": "fr-FR-HenriNeural", "whisper_device": "cuda:0",
+       "prosody_settings": {"baseline_window": 4, "pitch_semitones": 1.3, "pitch_lower_clip_factor": 0.7, "volume_pct": 10.0,
+                            "rate_percent": 10.0, "smoothing_alpha": 0.2, "max_jump_percent": 8, "end_punctuation_pause_ms": 500,
+                            "inter_syntagme_pause_factor": 1, "threshold_duration_before_slowing_down": 1.0, "slow_floor_per_sec": 2.0},
+       "steps_to_run": ["Measure & Build SSML"]}
+
+
+def test_measure_step_with_44k_recordings_and_16k_synthesis(engine, excerpts, tmp_path):
+    """The step on a voice that mixes sample rates (every real voice does): the 16 kHz synthesis is measured with the K-weighting
+    filter, block length and too-short rule of a meter built at 44.1 kHz, exactly as the reference does."""
+    rate, _ = excerpts
+    assert rate == 44100
+    voice, raw, pcm, rates, segs = _voice_with_mixed_rates(tmp_path, excerpts)
+    ap = AudioPipeline("v1", CFG, base=tmp_path, engine=engine)
+    res = ap.measure_prosody_and_build_ssml()
+    want = T.SsmlTagger(ap.settings, ap.azure_voice).run(segs, MixedRateOracle(pcm, rates, rate))
+    for a, b in zip(res.segment_stats, want.segment_stats):
+        assert a["segment"] == b["segment"] and a["d_nat"] == b["d_nat"] and a["d_syn"] == b["d_syn"]
+        assert abs(a["p_nat"] - b["p_nat"]) <= 1e-6 * max(b["p_nat"], 1.0)
+        assert abs(a["l_nat"] - b["l_nat"]) <= 1e-6 and abs(a["l_syn"] - b["l_syn"]) <= 1e-6
+        # ... and it is NOT what a meter at the data's own rate would say (the quirk is really mirrored)
+        own = O.get_lufs(pcm[("syn", a["segment"])], 16000, impl=O.lufs_numpy)
+        assert abs(own - b["l_syn"]) > 1e-3
+    for got_csv, df in ((ap.bdd_ssml_csv, want.bdd_ssml), (ap.bdd_syntagme_ssml_csv, want.bdd_syntagme_ssml),
+                        (ap.bdd_syntagme_synth_csv, want.bdd_syntagme_for_synth)):
+        p = tmp_path / ("want_" + got_csv.name)
+        df.to_csv(p, index=False)
+        assert got_csv.read_text(encoding="utf-8") == p.read_text(encoding="utf-8")
+
+
+def test_path_keyed_closures_drive_the_tagger(engine, excerpts, tmp_path):
+    """``ProsodySeam.closures()``: the four closures of Code/audioPipeline.py:314-361 with the reference's signatures (paths,
+    seconds, a meter object).  A measurement source that calls them the way the reference's loop does reproduces the CSVs of
+    the batched step; sentinels and fallbacks are the reference's."""
+    from prosody_control_french_tts_amd.audio_pipeline import ProsodySeam
+    rate, _ = excerpts
+    voice, raw, pcm, rates, segs = _voice_with_mixed_rates(tmp_path, excerpts)
+    (raw / "segment_ph3.wav").write_bytes(b"not a wav")                    # CouldntDecodeError fallback path of the reference
+    ap = AudioPipeline("v1", CFG, base=tmp_path, engine=engine)
+    batched = ap.measure_prosody_and_build_ssml()
+    seam = ProsodySeam(engine)
+    get_part_duration, get_median_pitch, get_lufs, get_duration = seam.closures()
+
+    class Meter:                                                          # what the reference passes: pyln.Meter(rate)
+        def __init__(self, r): self.rate = r
+
+    class Src(T.MeasurementSource):
+        def path(self, kind, seg): return (voice / "audio" if kind == "nat" else raw) / f"{seg}.wav"
+        def median_pitch(self, seg, t0=0.0, t1=None): return get_median_pitch(self.path("nat", seg), t0, t1)
+        def lufs(self, kind, seg, t0=0.0, t1=None):
+            meter = Meter(rate) if t1 is None else Meter(rates[("nat", seg)])
+            return get_lufs(self.path(kind, seg), meter, t0, t1)
+        def duration(self, kind, seg): return get_duration(self.path(kind, seg))
+        def part_duration(self, kind, seg, t0=0.0, t1=None): return get_part_duration(self.path(kind, seg), t0, t1)
+
+    res = T.SsmlTagger(ap.settings, ap.azure_voice).run(segs, Src())
+    for name, a, b in (("ssml", res.bdd_ssml, batched.bdd_ssml), ("syn", res.bdd_syntagme_ssml, batched.bdd_syntagme_ssml),
+                       ("synth", res.bdd_syntagme_for_synth, batched.bdd_syntagme_for_synth)):
+        pa, pb = tmp_path / f"a_{name}.csv", tmp_path / f"b_{name}.csv"
+        a.to_csv(pa, index=False); b.to_csv(pb, index=False)
+        assert pa.read_text(encoding="utf-8") == pb.read_text(encoding="utf-8")
+    # sentinels / conventions (SURVEY.md 8b "Prosody seams")
+    nat1 = voice / "audio" / "segment_ph1.wav"
+    assert isinstance(get_median_pitch(nat1), float) and isinstance(get_lufs(nat1, Meter(rate)), float)
+    silent = tmp_path / "silent.wav"; _write_wav(silent, np.zeros(rate, np.int16), rate)
+    assert get_median_pitch(silent) == 0.0                                 # no voiced frame
+    assert get_lufs(silent, rate) == float("-inf")                        # peak or 1.0, then log10(0)
+    empty = tmp_path / "empty.wav"; _write_wav(empty, np.zeros(0, np.int16), rate)
+    assert get_duration(empty) == 1e-4 and get_part_duration(nat1, 0.5, 0.5) == 1e-4
+    whole = get_lufs(nat1, Meter(rate))
+    assert get_lufs(nat1, Meter(rate), 0.2, 0.3) == whole                  # 0.1 s < 0.4 s block: whole-file fallback
+    assert abs(get_lufs(nat1, Meter(rate), 0.1, 0.9) - O.get_lufs(pcm[("nat", "segment_ph1")], rate, 0.1, 0.9, impl=O.lufs_numpy)) <= 1e-6
+    assert abs(get_median_pitch(nat1, 0.2, 1.0) - O.median_pitch(pcm[("nat", "segment_ph1")], rate, 0.2, 1.0)) <= 1e-6 * 600
+    with pytest.raises(H.CouldntDecodeError):
+        get_lufs(raw / "segment_ph3.wav", Meter(rate))
+    short = tmp_path / "short.wav"; _write_wav(short, pcm[("nat", "segment_ph1")][: rate // 10], rate)
+    with pytest.raises(ValueError):
+        get_lufs(short, Meter(rate))                                      # the whole file is shorter than a block: pyloudnorm's ValueError
+    seam.prefetch([(nat1, 0.3, 0.8)], [(nat1, rate, 0.3, 0.8)])            # planned queries: one batch, then served from the table
+    assert get_median_pitch(nat1, 0.3, 0.8) == seam.pitch_key(str(nat1), 0.3, 0.8)

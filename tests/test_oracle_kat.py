@@ -154,3 +154,46 @@ def test_stft_db_agrees_with_torch_stft():
     assert got.shape == want.shape == (513, 1 + len(y) // 256)
     live = want > -79.0
     assert np.max(np.abs(got[live] - want[live])) <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# EBU Tech 3341 (v3, 2016) "minimum requirements test signals" for integrated loudness, cases 1-5: 1 kHz sine sections at
+# stated dBFS levels, expected I = -23.0 / -33.0 LUFS +-0.1 for the STEREO files.  What is restated here: the level schedule
+# and the expected values.  Adapted to this path: one channel (a mono file reads 3.01 LU lower than the same sine on two
+# channels) and get_lufs's peak normalisation (Code/audioPipeline.py:349-350: the loudest section becomes 0 dBFS), so the
+# published targets translate to: loudest-section level (-3.01 LUFS for a 0 dBFS 1 kHz mono sine) plus the published
+# distance between target and loudest section.  Narrows, does not lift, "parity unpinned" for pyloudnorm.
+# ---------------------------------------------------------------------------------------------------------------
+EBU_3341 = {
+    # case: ([(dBFS, seconds), ...], published stereo target in LUFS)
+    1: ([(-23.0, 20.0)], -23.0),
+    2: ([(-33.0, 20.0)], -33.0),
+    3: ([(-36.0, 10.0), (-23.0, 60.0), (-36.0, 10.0)], -23.0),
+    4: ([(-72.0, 10.0), (-36.0, 10.0), (-23.0, 60.0), (-36.0, 10.0), (-72.0, 10.0)], -23.0),
+    5: ([(-26.0, 20.0), (-20.0, 20.1), (-26.0, 20.0)], -23.0),
+}
+
+
+def ebu_3341_signal(case, rate):
+    """int16 mono rendering of a case + the value get_lufs must return for it."""
+    sections, target = EBU_3341[case]
+    parts, t0 = [], 0
+    for db, secs in sections:
+        n = int(round(secs * rate))
+        t = (t0 + np.arange(n)) / rate
+        parts.append(10 ** (db / 20.0) * np.sin(2 * np.pi * 1000.0 * t)); t0 += n
+    x = np.round(np.concatenate(parts) * 32767.0).astype(np.int16)
+    loudest = max(db for db, _ in sections)
+    return x, -3.01 + (target - loudest)
+
+
+@pytest.mark.parametrize("rate", [48000, 16000])
+@pytest.mark.parametrize("case", [1, 2, 3, 4, 5])
+def test_lufs_ebu_tech_3341_minimum_requirements(case, rate):
+    x, want = ebu_3341_signal(case, rate)
+    got = O.lufs_c(x.astype(np.float64), rate)
+    assert abs(got - want) <= 0.1, (case, rate, got, want)
+    if case in (3, 4):
+        # the gates really act: without them the quiet sections would pull the average down by more than the tolerance
+        ungated = -0.691 + 10 * np.log10(np.mean((x / np.abs(x).max()) ** 2)) + 0.691
+        assert ungated < want - 0.5
