@@ -233,6 +233,11 @@ int pce_logmel_run_at(pce_ctx *ctx, int32_t n_mels, const int64_t *start_frames 
 int pce_logmel_fetch(pce_ctx *ctx, int32_t clip, float *out /* [n_mels][3000] */);
 int pce_whisper_load(pce_ctx *ctx, const pce_whisper_dims *dims, const float *weights, int64_t n_floats);
 int pce_whisper_encode_run(pce_ctx *ctx);
+/* Self-test of the GEMM kernel the encoder's projections run on (persistent 256 x 256 tiles, csrc/pce_gemm256.inc) on host arrays of bf16 bit
+ * patterns: C = epilogue(A[M][K] B[N][K]^T + bias).  epilogue 0: bias; 1: bias + exact GELU; 2: bias, written transposed per clip
+ * (rows_per_clip rows each, key axis padded to vt_sp): out[(clip N + n) vt_sp + t].  N % 256 == 0, K % 64 == 0, M >= 2048. */
+int pce_selftest_gemm(pce_ctx *ctx, const uint16_t *A, const uint16_t *B, const float *bias, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                      int32_t rows_per_clip, int32_t vt_sp, uint16_t *out);
 int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
 
 /* ---- R8: forced alignment of known text tokens (teacher-forced decoder + cross-attention DTW) ----
@@ -349,7 +354,7 @@ enum pce_kernel_id {
     PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_WHISPER_DECODE,
     /* the launches inside the composite entries above (whisper_encoder, whisper_align, bert_forward, whisper_decode_step),
      * each bracketed on its own so that a roofline figure divides one kernel's work by that kernel's own duration */
-    PCE_K_GEMM128, PCE_K_GEMM_WIDE, PCE_K_ATTENTION, PCE_K_LAYERNORM, PCE_K_COUNT
+    PCE_K_GEMM128, PCE_K_GEMM_WIDE, PCE_K_ATTENTION, PCE_K_LAYERNORM, PCE_K_GEMM_FLAT, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

@@ -117,6 +117,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->no_side = getenv("PCE_NO_AUX") != nullptr;
     c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
+    c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
     c->dbg_pitch_lds_fft = getenv("PCE_PITCH_LDS_FFT") != nullptr;
     c->dbg_pitch_tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) : -1;
     c->dbg_pitch = getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0;
@@ -340,7 +341,7 @@ const char *pce_kernel_name(int id)
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
         "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
-        "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm"};
+        "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

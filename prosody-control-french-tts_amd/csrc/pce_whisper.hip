@@ -579,6 +579,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *x, const float *
     }
 }
 
+#include "pce_gemm256.inc"
+
 // ---------------------------------------------------------------------------
 // attention forward, transposed formulation on v_mfma_f32_32x32x16_bf16.
 //   S^T = K Q^T   (keys on the accumulator rows, queries on its columns = lanes)
@@ -1163,7 +1165,7 @@ struct WhisperState {
     pce_whisper_dims dims{};
     bool loaded = false;
     DevBuf tables, logspec, clipmax, mel_tm, mel_start, w_bf16, w_f32, pos;
-    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab;
+    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab, delta;
     size_t vt_elems_zeroed = 0;
     // text decoder
     pce_whisper_text_dims tdims{};
@@ -1254,6 +1256,29 @@ int mel_setup(pce_ctx *c, WhisperState *w, int n_mels)
     return PCE_OK;
 }
 
+// Persistent 256 x 256 GEMM (pce_gemm256.inc) for the big projections: A dense [M][K], C bf16.  Returns false when the shape does not fit
+// (the caller then takes the tiled kernels).
+template <int EPI>
+bool launch_gemm_flat(pce_ctx *c, const bf16 *A, const bf16 *B, const float *bias, bf16 *C, int M, int N, int K, int ldc, int S = 1, int vt_sp = 0)
+{
+    if (!c->gemm_flat || N % F_T || K % F_K || M < 2048 || (int64_t)M * K * 2 >= (1ll << 32) || (int64_t)N * K * 2 >= (1ll << 32) ||
+        (int64_t)M * (EPI == FEPI_VT ? 1 : ldc) * 2 >= (1ll << 32) || N > 6144 || (EPI == FEPI_VT && (S % 4 || S < F_T)))
+        return false;
+    FArgs P{};
+    P.A = A; P.B = B; P.bias = bias; P.C = C; P.M = M; P.N = N; P.K = K; P.ldc = ldc; P.S = S; P.vt_sp = vt_sp;
+    const int tiles_n = N / F_T;
+    P.sn = 1;
+    for (int cand : {4, 3, 2}) if (tiles_n % cand == 0) { P.sn = cand; break; }
+    P.sm = 16; P.stagger = 20000;
+    const int lds = F_RING_BYTES + N * (int)sizeof(float);
+    static bool attr_done[3] = {false, false, false};
+    if (!attr_done[EPI]) { (void)hipFuncSetAttribute((const void *)k_gemm_flat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds > 147456 ? lds : 147456); attr_done[EPI] = true; }
+    const int grid = ((c->cu_count > 0 ? c->cu_count : 256) / 8) * 8;
+    KernelTimer kt(c, PCE_K_GEMM_FLAT, nullptr, 2.0 * M * (double)N * K);
+    hipLaunchKernelGGL((k_gemm_flat<EPI>), dim3((unsigned)grid), dim3(F_THREADS), lds, c->stream, P);
+    return true;
+}
+
 static unsigned long long *g_gemm_trace = nullptr;          // debugging aid: per-workgroup s_memtime stamps (tools only)
 template <int EPI>
 void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const bf16 *B, int M, int N, int K, const float *bias,
@@ -1315,7 +1340,7 @@ void pce_whisper_free(pce_ctx *c)
     if (!c->whisper) return;
     WhisperState *w = static_cast<WhisperState *>(c->whisper);
     DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->mel_start, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
-                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
+                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->delta, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
                       &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
                       &w->g_sk, &w->g_svt, &w->g_c_resid, &w->g_c_ln, &w->g_c_qkv, &w->g_c_attn, &w->g_c_q, &w->g_c_hidden, &w->g_c_tab,
@@ -1524,16 +1549,37 @@ int pce_whisper_encode_run(pce_ctx *c)
     // conv2 (stride 2): A row t' starts at padded row 2 t', K = 3 d, lda = 2 d; epilogue adds the positional embedding
     launch_gemm<EPI_GELU_POS_F32>(c, w->c1_out.as<bf16>(), 2 * (int64_t)d, (int64_t)(W_FRAMES + 2) * d, Wb + w->c2_w, W_CTX, d, 3 * d,
                                   Wf + w->c2_b, w->resid.as<float>(), d, (int64_t)W_CTX * d, n, w->pos.as<float>(), W_CTX);
+    // The big projections run on the persistent 256 x 256 kernel when the shape allows it (n_state % 256 == 0, a batch of at least a few
+    // clips).  On that path a branch (attention projection, MLP) leaves its output as a bf16 row block and the residual add is fused
+    // into the LayerNorm that follows (k_add_layernorm): one pass over the residual stream instead of the GEMM's read-modify-write
+    // plus the LayerNorm's read.
+    const bool flat = c->gemm_flat && d % F_T == 0 && M >= 2048 && (int64_t)M * 4 * d * 2 < (1ll << 32);
+    if (flat) PCE_HIP(c, w->delta.reserve(sizeof(bf16) * (size_t)M * d));
+    auto add_ln = [&](size_t w_off, size_t b_off, bool last) {
+        KernelTimer kt(c, PCE_K_LAYERNORM);
+        if (last)
+            hipLaunchKernelGGL((k_add_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(),
+                               Wf + w_off, Wf + b_off, M, d, w->final_out.as<float>(), 1e-5f);
+        else
+            hipLaunchKernelGGL((k_add_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(),
+                               Wf + w_off, Wf + b_off, M, d, w->ln_out.as<bf16>(), 1e-5f);
+    };
     for (int l = 0; l < L; l++) {
         const WhisperState::Layer &ly = w->layers[(size_t)l];
-        {
+        if (!flat || l == 0) {
             KernelTimer kt(c, PCE_K_LAYERNORM);
             hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln1_w,
                                Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
         }
-        // Q | K go to the row-major [M][2d] buffer, V is written transposed per head (pos carries the pointer)
-        launch_gemm<EPI_QKV>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 2 * d, 0, 1,
-                             reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX, 2 * d, AT_SP);
+        // Q | K go to the row-major [M][2d] buffer, V is written transposed per head
+        bool done = flat && launch_gemm_flat<FEPI_BF16>(c, w->ln_out.as<bf16>(), Wb + ly.qkv_w, Wf + ly.qkv_b, w->qkv.as<bf16>(), (int)M, 2 * d, d, 2 * d);
+        if (done) {
+            if (!launch_gemm_flat<FEPI_VT>(c, w->ln_out.as<bf16>(), Wb + ly.qkv_w + (size_t)2 * d * d, Wf + ly.qkv_b + 2 * d, w->vt.as<bf16>(), (int)M, d, d, 0,
+                                           W_CTX, AT_SP))
+                return pce_fail(c, PCE_E_LIMIT, "transposed-V projection does not fit the 256 x 256 kernel");
+        } else
+            launch_gemm<EPI_QKV>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 2 * d, 0, 1,
+                                 reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX, 2 * d, AT_SP);
         {
             AttnArgs a{};
             a.q = w->qkv.as<bf16>(); a.q_ld = 2 * d; a.k = w->qkv.as<bf16>() + d; a.k_ld = 2 * d;
@@ -1542,6 +1588,17 @@ int pce_whisper_encode_run(pce_ctx *c)
             a.out = w->attn.as<bf16>(); a.out_ld = d; a.causal = 0;
             KernelTimer kt(c, PCE_K_ATTENTION, nullptr, 4.0 * W_CTX * (double)W_CTX * d * n);
             hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+        }
+        if (flat) {
+            if (!launch_gemm_flat<FEPI_BF16>(c, w->attn.as<bf16>(), Wb + ly.out_w, Wf + ly.out_b, w->delta.as<bf16>(), (int)M, d, d, d))
+                return pce_fail(c, PCE_E_LIMIT, "attention projection does not fit the 256 x 256 kernel");
+            add_ln(ly.ln2_w, ly.ln2_b, false);
+            if (!launch_gemm_flat<FEPI_GELU>(c, w->ln_out.as<bf16>(), Wb + ly.m1_w, Wf + ly.m1_b, w->hidden.as<bf16>(), (int)M, 4 * d, d, 4 * d) ||
+                !launch_gemm_flat<FEPI_BF16>(c, w->hidden.as<bf16>(), Wb + ly.m2_w, Wf + ly.m2_b, w->delta.as<bf16>(), (int)M, d, 4 * d, d))
+                return pce_fail(c, PCE_E_LIMIT, "MLP does not fit the 256 x 256 kernel");
+            if (l + 1 < L) add_ln(w->layers[(size_t)l + 1].ln1_w, w->layers[(size_t)l + 1].ln1_b, false);
+            else add_ln(w->lnp_w, w->lnp_b, true);
+            continue;
         }
         launch_gemm<EPI_RESID_F32>(c, w->attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, w->resid.as<float>(), d, 0, 1);
         {
@@ -1552,7 +1609,7 @@ int pce_whisper_encode_run(pce_ctx *c)
         launch_gemm<EPI_GELU_BF16>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.m1_w, (int)M, 4 * d, d, Wf + ly.m1_b, w->hidden.as<bf16>(), 4 * d, 0, 1);
         launch_gemm<EPI_RESID_F32>(c, w->hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, (int)M, d, 4 * d, Wf + ly.m2_b, w->resid.as<float>(), d, 0, 1);
     }
-    {
+    if (!flat) {
         KernelTimer kt(c, PCE_K_LAYERNORM);
         hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + w->lnp_w,
                            Wf + w->lnp_b, M, d, w->final_out.as<float>());
@@ -1560,6 +1617,39 @@ int pce_whisper_encode_run(pce_ctx *c)
     PCE_HIP(c, hipGetLastError());
     w->n_clips_enc = n; w->g_xkv_clips = -1; w->g_cache_len = -1;
     return PCE_OK;
+}
+
+// Self-test hook of the persistent 256 x 256 GEMM: C = epilogue(A B^T + bias) on host arrays (bf16 bit patterns in, bf16 bit patterns out).
+// epilogue 0: bias, 1: bias + GELU, 2: bias, written transposed per clip (rows_per_clip rows, key axis padded to vt_sp): out[(clip N + n) vt_sp + t]
+int pce_selftest_gemm(pce_ctx *c, const uint16_t *A, const uint16_t *B, const float *bias, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                      int32_t rows_per_clip, int32_t vt_sp, uint16_t *out)
+{
+    if (!c || !A || !B || !out || M <= 0 || N <= 0 || K <= 0) return PCE_E_INVALID;
+    PCE_HIP(c, hipSetDevice(c->device));
+    const size_t n_out = epilogue == 2 ? (size_t)(M / rows_per_clip) * N * vt_sp : (size_t)M * N;
+    DevBuf dA, dB, dC, dbias;
+    PCE_HIP(c, dA.reserve((size_t)M * K * 2)); PCE_HIP(c, dB.reserve((size_t)N * K * 2)); PCE_HIP(c, dC.reserve(n_out * 2)); PCE_HIP(c, dbias.reserve((size_t)N * 4));
+    PCE_HIP(c, hipMemcpyAsync(dA.p, A, (size_t)M * K * 2, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dB.p, B, (size_t)N * K * 2, hipMemcpyHostToDevice, c->stream));
+    if (bias) PCE_HIP(c, hipMemcpyAsync(dbias.p, bias, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemsetAsync(dC.p, 0, n_out * 2, c->stream));
+    bool ok = false;
+    const float *bp = bias ? dbias.as<float>() : nullptr;
+    if (epilogue == 0) ok = launch_gemm_flat<FEPI_BF16>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, N);
+    else if (epilogue == 1) ok = launch_gemm_flat<FEPI_GELU>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, N);
+    else if (epilogue == 2) ok = launch_gemm_flat<FEPI_VT>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, 0, rows_per_clip, vt_sp);
+    int rc = PCE_OK;
+    if (!ok) rc = pce_fail(c, PCE_E_LIMIT, "shape not handled by the 256 x 256 kernel (N %% 256, K %% 64, M >= 2048)");
+    else {
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, dC.p, n_out * 2, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = pce_fail(c, PCE_E_DEVICE, "selftest gemm: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    dA.release(); dB.release(); dC.release(); dbias.release();
+    pce_profile_collect(c);
+    return rc;
 }
 
 int pce_whisper_encode_fetch(pce_ctx *c, int32_t clip, float *out)

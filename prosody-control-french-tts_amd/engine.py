@@ -96,7 +96,7 @@ SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
               "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
-              "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm"]
+              "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat"]
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -107,7 +107,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
            "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex",
-           "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_whisper_encode_fetch",
+           "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
 
@@ -165,6 +165,7 @@ def load_library() -> C.CDLL:
     lib.pce_logmel_fetch.argtypes = [vp, i32, vp]
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
     lib.pce_whisper_encode_run.argtypes = [vp]
+    lib.pce_selftest_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.pce_whisper_encode_fetch.argtypes = [vp, i32, vp]
     lib.pce_profile_enable.argtypes = [vp, C.c_int]
     lib.pce_profile_reset.argtypes = [vp]
@@ -405,6 +406,22 @@ class ProsodyEngine:
 
     def whisper_num_encoded(self) -> int:
         return getattr(self, "_n_encoded", 0)
+
+    def selftest_gemm(self, A, B, bias=None, epilogue: int = 0, rows_per_clip: int = 1, vt_sp: int = 0):
+        """C = epilogue(A B^T + bias) on the persistent 256 x 256 GEMM kernel; A [M][K], B [N][K] float arrays (rounded to bf16 here) ->
+        float32 result decoded from bf16 ([M][N], or [clips][N][vt_sp] for the transposed epilogue 2)."""
+        import torch
+        a = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float32)).to(torch.bfloat16).contiguous()
+        b = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float32)).to(torch.bfloat16).contiguous()
+        M, K = a.shape; N = b.shape[0]
+        n_out = (M // rows_per_clip) * N * vt_sp if epilogue == 2 else M * N
+        out = torch.zeros(n_out, dtype=torch.bfloat16)
+        bv = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        self._check(self._lib.pce_selftest_gemm(self._ctx, a.view(torch.int16).numpy().ctypes.data, b.view(torch.int16).numpy().ctypes.data,
+                                                bv.ctypes.data if bv is not None else None, M, N, K, int(epilogue), int(rows_per_clip), int(vt_sp),
+                                                out.view(torch.int16).numpy().ctypes.data))
+        res = out.float().numpy()
+        return res.reshape(M // rows_per_clip, N, vt_sp) if epilogue == 2 else res.reshape(M, N)
 
     def whisper_encode_fetch(self, clip: int) -> np.ndarray:
         out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)

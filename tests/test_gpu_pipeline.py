@@ -245,7 +245,7 @@ def _voice_with_mixed_rates(tmp_path, excerpts, n_seg=5):
         seg = f"segment_ph{k + 1}"
         nat = clips[name]
         syn = O.resample_int16(np.clip(np.roll(nat, 500).astype(np.int32) * 2 // 3, -32768, 32767).astype(np.int16), rate, 16000)
-        syn = syn[: int(len(syn) * rng.uniform(0.85, 1.0))]
+        syn = syn[: int(len(syn) * rng.uniform(0.93, 1.0))]             # (>= 0.4 s of the 44.1 kHz meter: 17 640 frames)
         _write_wav(voice / "audio" / f"{seg}.wav", nat, rate); _write_wav(raw / f"{seg}.wav", syn, 16000)
         pcm[("nat", seg)], pcm[("syn", seg)] = nat, syn
         rates[("nat", seg)], rates[("syn", seg)] = rate, 16000
@@ -308,6 +308,11 @@ def test_measure_step_with_44k_recordings_and_16k_synthesis(engine, excerpts, tm
         p = tmp_path / ("want_" + got_csv.name)
         df.to_csv(p, index=False)
         assert got_csv.read_text(encoding="utf-8") == p.read_text(encoding="utf-8")
+    # a synthesis of 1.0 s at 16 kHz is 16 000 frames: shorter than the 44.1 kHz meter's 0.4 s block (17 640 frames).  pyloudnorm raises
+    # ValueError there and the reference's get_lufs does not catch it; neither does the step
+    _write_wav(raw / "segment_ph2.wav", pcm[("syn", "segment_ph2")][:16000], 16000)
+    with pytest.raises(ValueError, match="block size"):
+        AudioPipeline("v1", CFG, base=tmp_path, engine=engine).measure_prosody_and_build_ssml()
 
 
 def test_path_keyed_closures_drive_the_tagger(engine, excerpts, tmp_path):

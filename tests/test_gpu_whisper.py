@@ -375,3 +375,48 @@ def test_c3_batch_of_256_is_clip_independent(engine):
         assert np.array_equal(paths_4[k]["text_indices"], paths_all[i]["text_indices"])
         assert np.array_equal(paths_4[k]["time_indices"], paths_all[i]["time_indices"])
         assert paths_all[i]["text_indices"][-1] == len(toks[i]) - 3 - 2 and paths_all[i]["time_indices"][-1] == frames[i] // 2 - 1
+
+
+@pytest.mark.parametrize("shape", [(3000, 1536, 768, 0), (3000, 3072, 768, 1), (6000, 768, 3072, 0), (3000, 768, 768, 2), (4100, 256, 64, 0)])
+def test_persistent_256_gemm_against_torch(engine, shape):
+    """The persistent 256 x 256 GEMM of the big encoder projections (pce_gemm256.inc) alone, through its self-test entry
+    point: C = epilogue(A B^T + bias) against torch fp32 on the bf16-rounded operands.  Tolerance: the bf16 rounding of
+    the OUTPUT (relative 2^-8 per element; 4e-3 relative L2 over the matrix, 2^-7 |x| + 1e-2 per element).  Shapes: the
+    four encoder projections of Whisper-small (bias, bias + exact GELU, K = 3072, transposed-V image with the key axis
+    padded to 1536), ragged M (last row tile partial) and the smallest legal N, K."""
+    import torch
+    M, N, K, epi = shape
+    rng = np.random.default_rng(M + N + K + epi)
+    A = rng.standard_normal((M, K)).astype(np.float32); B = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    a = torch.from_numpy(A).to(torch.bfloat16).float(); b = torch.from_numpy(B).to(torch.bfloat16).float()
+    want = a @ b.T + torch.from_numpy(bias)
+    if epi == 1: want = torch.nn.functional.gelu(want)
+    want = want.numpy()
+    S = 1500 if epi == 2 else 1
+    got = engine.selftest_gemm(A, B, bias, epi, S, 1536)
+    if epi == 2:
+        assert got.shape == (M // S, N, 1536)
+        assert not got[:, :, S:].any()                                 # the padding of the key axis is never written
+        got = np.concatenate([got[c, :, :S].T for c in range(M // S)])
+    assert np.isfinite(got).all()
+    err = np.abs(got - want)
+    assert np.linalg.norm(err) / np.linalg.norm(want) <= 4e-3
+    assert (err <= np.abs(want) * 2.0 ** -7 + 1e-2).all(), np.argwhere(err > np.abs(want) * 2.0 ** -7 + 1e-2)[:8]
+
+
+def test_persistent_256_gemm_is_deterministic_and_row_count_independent(engine):
+    """Each output element is one lane's fixed-order sum: a row block gives the same BITS whether 6 000 or 96 000 rows are in
+    the product (other tile order, other workgroup, other ring phase), run after run.  (Two scheduling bugs showed up as
+    exactly this kind of difference: a store overtaken by the next conversion, and the first K-step of a workgroup's first tile
+    read before it had landed.)"""
+    rng = np.random.default_rng(0)
+    for (N, K, epi) in [(768, 768, 0), (768, 3072, 0), (1536, 768, 1), (768, 768, 2)]:
+        M1, M2 = 6000, 96000
+        A = rng.standard_normal((M2, K), dtype=np.float32); B = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        small = engine.selftest_gemm(A[:M1], B, bias, epi, 1500, 1536)
+        head = (lambda x: x[:4]) if epi == 2 else (lambda x: x[:M1])
+        for _ in range(3):
+            assert np.array_equal(head(engine.selftest_gemm(A, B, bias, epi, 1500, 1536)), small), (N, K, epi)
+        assert np.array_equal(engine.selftest_gemm(A[:M1], B, bias, epi, 1500, 1536), small)

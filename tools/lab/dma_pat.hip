@@ -60,10 +60,12 @@ int main()
     const size_t big = (size_t)3 << 30;
     char *buf; CK(hipMalloc(&buf, big + (1 << 20))); CK(hipMemset(buf, 1, big));
     u32 *out; CK(hipMalloc(&out, 512 * 512 * 4));
-    run<128, 1>(buf, 1536, 8, out, 0, 512, 0); run<128, 3>(buf, 1536, 8, out, 0, 512, 0);
-    run<128, 1>(buf, 1536, 8, out, 0, 256, 65536); run<128, 2>(buf, 1536, 8, out, 0, 256, 65536); run<128, 3>(buf, 1536, 8, out, 0, 256, 65536); run<128, 4>(buf, 1536, 8, out, 0, 256, 65536);
-    run<64, 1>(buf, 1536, 8, out, 0, 512, 0); run<64, 3>(buf, 1536, 8, out, 0, 512, 0);
-    run<64, 1>(buf, 1536, 8, out, 0, 256, 65536); run<64, 3>(buf, 1536, 8, out, 0, 256, 65536); run<64, 4>(buf, 1536, 8, out, 0, 256, 65536);
-    run<256, 1>(buf, 1536, 8, out, 0, 256, 65536); run<256, 3>(buf, 1536, 8, out, 0, 256, 65536);
+    // row pitch sweep (do equal offsets in every row camp on a subset of the L2 channels?): 128-B segments, 8 siblings, 3 stages in flight
+    for (int ld : {1536, 1664, 1792, 2048, 2176, 3072, 3200, 6144, 6272, 128})
+        run<128, 3>(buf, ld, 8, out, 0, 512, 0);
+    for (int ld : {1536, 1664, 6144, 6272}) run<128, 3>(buf, ld, 4, out, 0, 512, 0);
+    for (int ld : {1536, 1664, 6144, 6272}) run<128, 3>(buf, ld, 16, out, 0, 512, 0);
+    for (int ld : {1536, 1664, 256}) run<256, 3>(buf, ld, 8, out, 0, 256, 65536);
+    for (int ld : {1536, 1664}) run<64, 3>(buf, ld, 8, out, 0, 512, 0);
     return 0;
 }
