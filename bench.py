@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (never the 2:1-sparsity figure)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s fp32 vector rate (AMD's MI355X fp64 vector figure; the guide has no fp64 row)
 VALU_F64_PEAK_TFLOPS = 78.6     # fp64 vector peak (79 TF/s)
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 COMPOSITE = ("whisper_encoder", "whisper_align", "bert_forward", "whisper_decode_step")   # brackets around several launches
@@ -430,6 +431,14 @@ def run_rank(args, world, rank, local_rank):
                 ach = nbytes / (ms * 1e-3) / 1e9
                 rows.append({"stage": name, "kernels": present, "dominant_kernel": dom, "ms_per_step": ms, "bound": "hbm",
                              "algorithmic_bytes": nbytes, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+                if "k_pitch_frames" in present and kt["k_pitch_frames"].get("achieved_tflops"):
+                    # the frame kernel is fp64-VALU work (windowing + two real FFTs per frame, Praat's operation count), not HBM traffic:
+                    # its rate against the 78.6 TFLOP/s vector fp64 peak is the meaningful fraction of this stage
+                    f = kt["k_pitch_frames"]
+                    rows[-1].update({"achieved_tflops_f64": f["achieved_tflops"], "peak_tflops_f64": FP64_VECTOR_PEAK_TFLOPS,
+                                     "frac_f64": f["achieved_tflops"] / FP64_VECTOR_PEAK_TFLOPS,
+                                     "f64_note": "k_pitch_frames only: algorithmic flops per frame (3 nw + 5 nfft log2 nfft + 1.5 nfft + maxlag) x "
+                                                 "frames / its launch duration; the refinement (data-dependent Brent iterations) is not counted"})
             else:
                 ach = flops / (ms * 1e-3) / 1e12
                 rows.append({"stage": name, "kernels": present, "dominant_kernel": dom, "ms_per_step": ms, "bound": "mfma",

@@ -1542,7 +1542,10 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             const unsigned int list_cap = (unsigned int)(div_up(nb, RF_LISTS) * P.fpb * (PI_MAXC - 1));
             PCE_HIP(c, hipMemsetAsync(item_count, 0, cnt_bytes, c->stream));
             {
-                KernelTimer t(c, PCE_K_PITCH_FRAMES);
+                // algorithmic fp64 work of a frame (Praat's formulation): mean removal + window (3 nw), two real FFTs of nfft points
+                // (2.5 nfft log2 nfft each), the power spectrum (3 nfft / 2), the window-autocorrelation division (maxlag)
+                const double f_flops = 3.0 * P.nw + 5.0 * P.nfft * std::log2((double)P.nfft) + 1.5 * P.nfft + (double)P.maxlag;
+                KernelTimer t(c, PCE_K_PITCH_FRAMES, nullptr, f_flops * (double)total);
                 auto launch = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * wpb), lds, c->stream, c->d_pcm,
                                        c->pi_meta.as<PiSlice>(), c->pi_work.as<PiWork>(), (int)c->pi_n_work, P,

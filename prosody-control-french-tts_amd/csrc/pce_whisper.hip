@@ -1619,6 +1619,16 @@ int pce_whisper_encode_run(pce_ctx *c)
     return PCE_OK;
 }
 
+// Cross-attention keys (rows, [Ma][d]) and values (transposed per clip, key axis padded to AT_SP) of one decoder layer from the
+// encoded audio: W = [K weights | V weights] (2d rows of d).  On the persistent 256 x 256 kernel when the shape fits.
+static void project_cross_kv(pce_ctx *c, const bf16 *enc, int Ma, int d, const bf16 *W, const float *bias, bf16 *xk, bf16 *xvt)
+{
+    if (launch_gemm_flat<FEPI_BF16>(c, enc, W, bias, xk, Ma, d, d, d)) {
+        if (launch_gemm_flat<FEPI_VT>(c, enc, W + (size_t)d * d, bias + d, xvt, Ma, d, d, 0, W_CTX, AT_SP)) return;
+    }
+    launch_gemm<EPI_QKV>(c, enc, d, 0, W, Ma, 2 * d, d, bias, xk, d, 0, 1, reinterpret_cast<const float *>(xvt), W_CTX, d, AT_SP);
+}
+
 // Self-test hook of the persistent 256 x 256 GEMM: C = epilogue(A B^T + bias) on host arrays (bf16 bit patterns in, bf16 bit patterns out).
 // epilogue 0: bias, 1: bias + GELU, 2: bias, written transposed per clip (rows_per_clip rows, key axis padded to vt_sp): out[(clip N + n) vt_sp + t]
 int pce_selftest_gemm(pce_ctx *c, const uint16_t *A, const uint16_t *B, const float *bias, int32_t M, int32_t N, int32_t K, int32_t epilogue,
@@ -1849,8 +1859,7 @@ int pce_whisper_align_run(pce_ctx *c, const int32_t *tokens, const int32_t *toke
         launch_gemm<EPI_BF16>(c, w->d_ln.as<bf16>(), d, 0, Wb + ly.xq_w, (int)Mt, d, d, Wf + ly.xq_b, w->d_q.as<bf16>(), d, 0, 1);
         if (xkv_cached) { xk = w->g_xk.as<bf16>() + xk_cl * (size_t)l; xvt = w->g_xvt.as<bf16>() + xvt_cl * (size_t)l; }
         else
-            launch_gemm<EPI_QKV>(c, w->d_enc_bf16.as<bf16>(), d, 0, Wb + ly.xkv_w, (int)Ma, 2 * d, d, Wf + ly.xkv_b, xk, d, 0, 1,
-                                 reinterpret_cast<const float *>(xvt), W_CTX, d, AT_SP);
+            project_cross_kv(c, w->d_enc_bf16.as<bf16>(), (int)Ma, d, Wb + ly.xkv_w, Wf + ly.xkv_b, xk, xvt);
         attn(w->d_q.as<bf16>(), d, xk, d, xvt, (int64_t)d * AT_SP, AT_SP, A0, AL, 0);
         const int ns_l = layer_first[(size_t)l + 1] - layer_first[(size_t)l];
         if (ns_l > 0) {
@@ -2007,8 +2016,8 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
                            w->d_enc_bf16.as<bf16>(), Ma * d);
         for (int l = 0; l < L; l++) {
             const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
-            launch_gemm<EPI_QKV>(c, w->d_enc_bf16.as<bf16>(), d, 0, Wb + ly.xkv_w, (int)Ma, 2 * d, d, Wf + ly.xkv_b, w->g_xk.as<bf16>() + xk_l * (size_t)l, d, 0, 1,
-                                 reinterpret_cast<const float *>(w->g_xvt.as<bf16>() + xvt_l * (size_t)l), W_CTX, d, AT_SP);
+            project_cross_kv(c, w->d_enc_bf16.as<bf16>(), (int)Ma, d, Wb + ly.xkv_w, Wf + ly.xkv_b, w->g_xk.as<bf16>() + xk_l * (size_t)l,
+                             w->g_xvt.as<bf16>() + xvt_l * (size_t)l);
         }
         w->g_xkv_clips = n;
     }
