@@ -238,6 +238,12 @@ int pce_whisper_encode_run(pce_ctx *ctx);
  * (rows_per_clip rows each, key axis padded to vt_sp): out[(clip N + n) vt_sp + t].  N % 256 == 0, K % 64 == 0, M >= 2048. */
 int pce_selftest_gemm(pce_ctx *ctx, const uint16_t *A, const uint16_t *B, const float *bias, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                       int32_t rows_per_clip, int32_t vt_sp, uint16_t *out);
+/* Self-test of the attention kernel (64-wide heads; csrc/pce_whisper.hip k_attention_lean) on host arrays of bf16 bit patterns: clips x
+ * heads independent problems, q [clips][q_len][heads * 64], k and v [clips][k_len][heads * 64], out like q; softmax(q k^T / 8) v with the
+ * causal mask when causal != 0.  mode 0: the kernel as the engine runs it (fixed softmax reference, exact fallback), 1: its exact
+ * path only, 2: the round-1 kernel.  *fell_back (may be NULL): number of workgroups that had to take the exact path (mode 0). */
+int pce_selftest_attention(pce_ctx *ctx, const uint16_t *q, const uint16_t *k, const uint16_t *v, int32_t clips, int32_t heads, int32_t q_len,
+                           int32_t k_len, int32_t causal, int32_t mode, uint16_t *out, int32_t *fell_back);
 int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
 
 /* ---- R8: forced alignment of known text tokens (teacher-forced decoder + cross-attention DTW) ----

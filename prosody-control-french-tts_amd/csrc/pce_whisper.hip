@@ -605,6 +605,7 @@ struct AttnArgs {
     const int *q_row0, *q_len, *k_row0, *k_len;   // per clip
     bf16 *out; int64_t out_ld;              // out + (q_row0[c] + i) * out_ld + head * 64
     int causal;                             // key j visible to query i only if j <= i
+    int *fell_back;                         // (self-test only, else null) counts the workgroups of k_attention_lean that re-ran on the exact path
 };
 
 __device__ __forceinline__ void stage_kv(const bf16 *__restrict__ kbase, int64_t kld, int key0, int key_max,
@@ -778,6 +779,207 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs A)
                 *reinterpret_cast<bf16x4 *>(op + 32 * t + 8 * g + 4 * h) = v4;
             }
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_attention_lean: the same product with less than half of k_attention's vector instructions per tile.  Per 64-key tile a wave issues
+// 16 MFMAs and, in k_attention, about 200 VALU instructions; MFMAs and VALU instructions of all waves of a SIMD share one issue port
+// (v_fma 4 cycles, v_exp 8, an MFMA 8 of its 32: MI355X_MICROARCH.md "vector-instruction ISSUE cost"), and with three waves per SIMD the
+// PMC counters put k_attention's issue port at 96 % busy (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = 0.32 per wave): it is instruction-count
+// bound.  Removed from the tile loop:
+//   * the running maximum.  exp2(s c - m) needs SOME reference m per query, not the maximum: softmax is invariant under the choice and
+//     fp32 / bf16 share an 8-bit exponent, so with m fixed at the query's maximum over TILE 0 nothing is lost until a later score exceeds
+//     m by 127 / c.  That is detected (a non-finite row sum) and the workgroup then runs again on the exact path (EXACT = true: running
+//     maximum, accumulator rescale, VALU row sums) -- never on Whisper's logits; tests drive it with synthetic ones and force it;
+//   * the row sums: a 17th..20th MFMA per tile against a constant "row 0 = ones" fragment accumulates sum_j P[q][j] in the matrix pipe
+//     (which has slack) instead of 32 v_add / 16 v_pk_add (which has none); the sums are over the bf16 P the second product consumes;
+//   * address arithmetic: K / V^T tiles arrive by LDS-DMA through buffer resources (constant per-lane offsets, one scalar offset per
+//     tile; rows past the last key read as zeros and are masked like any invisible key), fragment addresses are loop invariants.
+// Same workgroup shape, ring and register budget as k_attention (4 waves x 32 queries, 3 slots = 48 KB, three workgroups per CU).
+// Measured, 256 clips x 12 heads x 1500^2: 2.56 -> 2.25 ms per launch.  Tried on the way and dropped: the next tile's S^T MFMAs
+// interleaved with this tile's exponentials inside one wave (two score sets in registers, 4 slots, two workgroups per CU): 2.59 ms with or
+// without the instruction diet -- waves then wait on LDS-DMA / barriers (SQ_WAIT_ANY 0.41) with too few partners to cover them; the same
+// with eight waves per workgroup (half the DMA instructions per wave): 3.0 ms.
+// ---------------------------------------------------------------------------
+template <bool EXACT>
+__device__ __forceinline__ bool attn_block(const AttnArgs &A, bf16 *smem)
+{
+    constexpr int NS = 3, DPW = 4;                               // ring slots; DMA wave-instructions per wave and tile (16 pieces of 1 KB, 4 waves)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, clip = blockIdx.z;
+    const int Sq = A.q_len[clip], Sk = A.k_len[clip];
+    const int q0 = blockIdx.x * AT_QB + wv * 32;
+    const bf16 *qbase = A.q + (int64_t)A.q_row0[clip] * A.q_ld + head * 64;
+    const bf16 *kbase = A.k + (int64_t)A.k_row0[clip] * A.k_ld + head * 64;
+    const bf16 *vtbase = A.vt + (int64_t)clip * A.vt_clip + (int64_t)head * 64 * A.vt_sp;
+    const int kld = (int)A.k_ld, vsp = A.vt_sp;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(kbase), 0, ((Sk - 1) * kld + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(vtbase), 0, 64 * vsp * 2, 0x00020000);
+    // a tile = 8 pieces of K (8 keys x 128 B each) + 8 pieces of V^T (8 rows of d); wave w moves pieces w and w + 4 of both
+    int voffK[2], voffV[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = (wv + 4 * i) * 8 + (lane >> 3), c8 = swz_chunk(row, lane & 7) * 8;
+        voffK[i] = (row * kld + c8) * 2; voffV[i] = (row * vsp + c8) * 2;
+    }
+    auto stage = [&](int t) {                                    // tile t -> slot t % NS
+        bf16 *sK = smem + (t % NS) * (2 * 64 * 64), *sV = sK + 64 * 64;
+        const int key0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void *)(sK + (wv + 4 * i) * 8 * 64), 16, voffK[i], key0 * kld * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void *)(sV + (wv + 4 * i) * 8 * 64), 16, voffV[i], key0 * 2, 0, 0);
+        }
+    };
+    bf16x8 qf[4];
+    {
+        int qr = q0 + r; if (qr >= Sq) qr = Sq - 1;
+        const bf16 *qp = qbase + (int64_t)qr * A.q_ld;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) qf[s4] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s4 + 8 * h);
+    }
+    auto fzero = [] { f32x16 z;
+#pragma unroll
+        for (int e = 0; e < 16; e++) z[e] = 0.f;
+        return z; };
+    bf16x8 ones;                                                 // A fragment "row 0 = ones, rows 1..31 = 0" of the row-sum MFMA
+#pragma unroll
+    for (int j = 0; j < 8; j++) ones[j] = (bf16)(r == 0 ? 1.0f : 0.0f);
+    f32x16 o[2], osum = fzero();
+    o[0] = fzero(); o[1] = fzero();
+    float m_run = -1e30f, l_run = 0.f;
+    const float sl2 = 0.125f * 1.4426950408889634f;               // softmax scale * log2(e): exp(x) = exp2(x log2 e)
+    const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): swap bits 2 and 3 (see k_attention)
+    int k_need = Sk;
+    if (A.causal) k_need = min(Sk, (int)blockIdx.x * AT_QB + AT_QB);
+    const int nt = (k_need + 63) / 64;
+    const int my_q = q0 + r;
+    int kaddr[2][4], vaddr[2][4];                                // LDS addresses of this lane's fragments inside a slot (elements)
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const int row = u * 32 + pr;
+            kaddr[u][s4] = row * 64 + swz_chunk(row, 2 * s4 + h) * 8;
+        }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {                             // c = 2 u + s2: keys u*32 + 16 s2 + 8 h .. + 7
+            const int row = t * 32 + r;
+            vaddr[t][c] = 64 * 64 + row * 64 + swz_chunk(row, 2 * c + h) * 8;
+        }
+    stage(0);
+    if (nt > 1) stage(1);
+    for (int kt = 0; kt < nt; kt++) {
+        // tile kt landed (each wave issues DPW instructions per tile, in tile order); everyone is done with tile kt-1, whose slot tile kt+2 takes
+        if (kt + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0F70 | DPW); else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nt) stage(kt + 2);
+        const bf16 *sC = smem + (kt % NS) * (2 * 64 * 64);
+        f32x16 sc[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+                sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&sC[kaddr[u][s4]]), qf[s4], s4 == 0 ? fzero() : sc[u], 0, 0, 0);
+        // edge tiles (last keys of the clip, the causal diagonal): invisible scores become -1e30 (unscaled), and exp2(-1e30 c - m) = 0 for
+        // any finite m; tile 0 always holds a visible key for every query, so m is finite from then on
+        if ((kt * 64 + 63 >= Sk) || (A.causal && kt * 64 + 63 > q0)) {                          // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int rho = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int key = kt * 64 + u * 32 + ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1));
+                    const bool vis = key < Sk && (!A.causal || key <= my_q);
+                    sc[u][e] = vis ? sc[u][e] : -1e30f;
+                }
+        }
+        if (EXACT || kt == 0) {
+            float m0 = sc[0][0], m1 = sc[0][1], m2 = sc[1][0], m3 = sc[1][1];
+#pragma unroll
+            for (int e = 2; e < 16; e += 2) { m0 = fmaxf(m0, sc[0][e]); m1 = fmaxf(m1, sc[0][e + 1]); m2 = fmaxf(m2, sc[1][e]); m3 = fmaxf(m3, sc[1][e + 1]); }
+            float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            mx = mx > -1e29f ? mx * sl2 : -1e30f;
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                const float corr = __builtin_amdgcn_exp2f(m_run - m_new);          // (tile 0: everything it scales is still zero)
+                l_run *= corr;
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) o[t][e] *= corr;
+                m_run = m_new;
+            }
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[u][e], sl2, -m_run)), p1 = __builtin_amdgcn_exp2f(fmaf(sc[u][e + 1], sl2, -m_run));
+                sc[u][e] = p0; sc[u][e + 1] = p1;
+                if (EXACT) { if (u == 0) { s0 += p0; s1 += p1; } else { s2 += p0; s3 += p1; } }
+            }
+        if (EXACT) {
+            float sum = (s0 + s1) + (s2 + s3);
+            sum += __shfl_xor(sum, 32, 64);
+            l_run += sum;
+        }
+        // O^T += V^T P^T (and the row sums): k-step c = 2 u + s2 covers keys u*32 + 16 s2 .. +15 (in pi order); B = registers 8 s2 .. 8 s2 + 7
+        bf16x8 vf[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) vf[t][c] = *reinterpret_cast<const bf16x8 *>(&sC[vaddr[t][c]]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; j++) pf[j] = (bf16)sc[c >> 1][8 * (c & 1) + j];
+#pragma unroll
+            for (int t = 0; t < 2; t++) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][c], pf, o[t], 0, 0, 0);
+            if (!EXACT) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, osum, 0, 0, 0);
+        }
+    }
+    if (!EXACT) l_run = __shfl(osum[0], r, 64);                  // row 0 of the row-sum product sits in register 0 of the lower lane half
+    const bool ok = EXACT || (l_run > 0.f && l_run < 3.0e38f) || my_q >= Sq;
+    if (!EXACT && __syncthreads_or(!ok)) return false;           // some row overflowed its fixed reference: the workgroup runs again, exactly
+    // O^T[d][q]: this lane owns query q0 + r; d = 32 t + (e & 3) + 8 (e >> 2) + 4 h -> runs of 4 consecutive d
+    if (my_q < Sq) {
+        const float inv = 1.0f / l_run;
+        bf16 *op = A.out + ((int64_t)A.q_row0[clip] + my_q) * A.out_ld + head * 64;
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                bf16x4 v4;
+#pragma unroll
+                for (int i = 0; i < 4; i++) v4[i] = (bf16)(o[t][4 * g + i] * inv);
+                *reinterpret_cast<bf16x4 *>(op + 32 * t + 8 * g + 4 * h) = v4;
+            }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256, 3) void k_attention_lean(AttnArgs A, int force_exact)
+{
+    __shared__ __attribute__((aligned(1024))) bf16 smem[3 * 2 * 64 * 64];               // [slot][K | V^T][64][64] = 48 KiB
+    if ((int)blockIdx.x * AT_QB >= A.q_len[blockIdx.z]) return;
+    if (!force_exact && attn_block<false>(A, smem)) return;
+    if (!force_exact && A.fell_back && threadIdx.x == 0) atomicAdd(A.fell_back, 1);
+    __syncthreads();
+    attn_block<true>(A, smem);
+}
+
+static void launch_attention(pce_ctx *c, dim3 grid, const AttnArgs &a)
+{
+    if (c->attn_mode == 0) hipLaunchKernelGGL(k_attention, grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_attention_lean, grid, dim3(256), 0, c->stream, a, c->attn_mode == 2 ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1587,7 +1789,7 @@ int pce_whisper_encode_run(pce_ctx *c)
             a.q_row0 = a.k_row0 = w->enc_tab.as<int>(); a.q_len = a.k_len = w->enc_tab.as<int>() + n;
             a.out = w->attn.as<bf16>(); a.out_ld = d; a.causal = 0;
             KernelTimer kt(c, PCE_K_ATTENTION, nullptr, 4.0 * W_CTX * (double)W_CTX * d * n);
-            hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+            launch_attention(c, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), a);
         }
         if (flat) {
             if (!launch_gemm_flat<FEPI_BF16>(c, w->attn.as<bf16>(), Wb + ly.out_w, Wf + ly.out_b, w->delta.as<bf16>(), (int)M, d, d, d))
@@ -1627,6 +1829,52 @@ static void project_cross_kv(pce_ctx *c, const bf16 *enc, int Ma, int d, const b
         if (launch_gemm_flat<FEPI_VT>(c, enc, W + (size_t)d * d, bias + d, xvt, Ma, d, d, 0, W_CTX, AT_SP)) return;
     }
     launch_gemm<EPI_QKV>(c, enc, d, 0, W, Ma, 2 * d, d, bias, xk, d, 0, 1, reinterpret_cast<const float *>(xvt), W_CTX, d, AT_SP);
+}
+
+// V rows [clips][k_len][heads * 64] -> the V^T image the attention kernels read: [clip][head * 64 + d][sp] (key axis padded with zeros)
+__global__ void k_selftest_vt(const bf16 *__restrict__ v, int k_len, int hd, int sp, int64_t n, bf16 *__restrict__ vt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % hd); const int64_t r = i / hd; const int t = (int)(r % k_len); const int64_t clip = r / k_len;
+    vt[(clip * hd + col) * sp + t] = v[i];
+}
+
+// Self-test hook of the attention kernels (see pce.h)
+int pce_selftest_attention(pce_ctx *c, const uint16_t *q, const uint16_t *k, const uint16_t *v, int32_t clips, int32_t heads, int32_t q_len,
+                           int32_t k_len, int32_t causal, int32_t mode, uint16_t *out, int32_t *fell_back)
+{
+    if (!c || !q || !k || !v || !out || clips <= 0 || heads <= 0 || q_len <= 0 || k_len <= 0 || mode < 0 || mode > 2) return PCE_E_INVALID;
+    PCE_HIP(c, hipSetDevice(c->device));
+    const int hd = heads * 64, sp = div_up(k_len, 64) * 64;
+    const size_t nq = (size_t)clips * q_len * hd, nk = (size_t)clips * k_len * hd, nvt = (size_t)clips * hd * sp;
+    DevBuf dq, dk, dv, dvt, dout, dtab, dcnt;
+    PCE_HIP(c, dq.reserve(nq * 2 + 64)); PCE_HIP(c, dk.reserve(nk * 2 + 64)); PCE_HIP(c, dv.reserve(nk * 2 + 64)); PCE_HIP(c, dvt.reserve(nvt * 2 + 128));
+    PCE_HIP(c, dout.reserve(nq * 2 + 64)); PCE_HIP(c, dtab.reserve(sizeof(int) * 4 * (size_t)clips)); PCE_HIP(c, dcnt.reserve(sizeof(int)));
+    std::vector<int> tab((size_t)4 * clips);
+    for (int i = 0; i < clips; i++) { tab[(size_t)i] = i * q_len; tab[(size_t)clips + i] = q_len; tab[(size_t)2 * clips + i] = i * k_len; tab[(size_t)3 * clips + i] = k_len; }
+    PCE_HIP(c, hipMemcpyAsync(dq.p, q, nq * 2, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dk.p, k, nk * 2, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dv.p, v, nk * 2, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dtab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemsetAsync(dvt.p, 0, nvt * 2 + 128, c->stream));
+    PCE_HIP(c, hipMemsetAsync(dout.p, 0, nq * 2, c->stream));
+    PCE_HIP(c, hipMemsetAsync(dcnt.p, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_selftest_vt, dim3((unsigned)div_up((int64_t)nk, 256)), dim3(256), 0, c->stream, dv.as<bf16>(), k_len, hd, sp, (int64_t)nk, dvt.as<bf16>());
+    AttnArgs a{};
+    a.q = dq.as<bf16>(); a.q_ld = hd; a.k = dk.as<bf16>(); a.k_ld = hd; a.vt = dvt.as<bf16>(); a.vt_clip = (int64_t)hd * sp; a.vt_sp = sp;
+    a.q_row0 = dtab.as<int>(); a.q_len = a.q_row0 + clips; a.k_row0 = a.q_row0 + 2 * clips; a.k_len = a.q_row0 + 3 * clips;
+    a.out = dout.as<bf16>(); a.out_ld = hd; a.causal = causal; a.fell_back = dcnt.as<int>();
+    const dim3 grid((unsigned)div_up(q_len, AT_QB), (unsigned)heads, (unsigned)clips);
+    if (mode == 2) hipLaunchKernelGGL(k_attention, grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_attention_lean, grid, dim3(256), 0, c->stream, a, mode);
+    PCE_HIP(c, hipGetLastError());
+    int cnt = 0;
+    PCE_HIP(c, hipMemcpyAsync(out, dout.p, nq * 2, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(&cnt, dcnt.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    if (fell_back) *fell_back = cnt;
+    return PCE_OK;
 }
 
 // Self-test hook of the persistent 256 x 256 GEMM: C = epilogue(A B^T + bias) on host arrays (bf16 bit patterns in, bf16 bit patterns out).
@@ -1842,7 +2090,7 @@ int pce_whisper_align_run(pce_ctx *c, const int32_t *tokens, const int32_t *toke
         AttnArgs a{};
         a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
         a.q_row0 = T0; a.q_len = TL; a.k_row0 = k0; a.k_len = kl; a.out = w->d_attn.as<bf16>(); a.out_ld = d; a.causal = causal;
-        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+        launch_attention(c, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), a);
     };
     for (int l = 0; l < L; l++) {
         const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
@@ -2064,7 +2312,7 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
             AttnArgs a{};
             a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
             a.q_row0 = Q0; a.q_len = QL; a.k_row0 = k0; a.k_len = kl; a.out = w->g_c_attn.as<bf16>(); a.out_ld = d; a.causal = 0;
-            hipLaunchKernelGGL(k_attention, dim3(1u, (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+            launch_attention(c, dim3(1u, (unsigned)H, (unsigned)n), a);
         };
         auto cln = [&](size_t w_off, size_t b_off) {
             hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w_off, Wf + b_off,
@@ -2098,7 +2346,7 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
         AttnArgs a{};
         a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
         a.q_row0 = T0; a.q_len = TL; a.k_row0 = k0; a.k_len = kl; a.out = w->d_attn.as<bf16>(); a.out_ld = d; a.causal = causal;
-        hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+        launch_attention(c, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), a);
     };
     auto ln = [&](size_t w_off, size_t b_off) {
         hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(Mt, 4)), dim3(256), 0, c->stream, w->d_resid.as<float>(), Wf + w_off, Wf + b_off,
@@ -2282,7 +2530,7 @@ int pce_bert_run(pce_ctx *c, const int32_t *input_ids, const int32_t *offsets, i
             a.vt = b.vt.as<bf16>(); a.vt_clip = (int64_t)d * SPD; a.vt_sp = SPD;
             a.q_row0 = a.k_row0 = T0; a.q_len = a.k_len = TL;    // keys beyond the sequence length are masked (right padding)
             a.out = b.attn.as<bf16>(); a.out_ld = d; a.causal = 0;
-            hipLaunchKernelGGL(k_attention, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+            launch_attention(c, dim3((unsigned)div_up(T_pad, AT_QB), (unsigned)H, (unsigned)n), a);
         }
         launch_gemm<EPI_RESID_F32>(c, b.attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, b.resid.as<float>(), d, 0, 1);
         ln(ly.ln1_w, ly.ln1_b);

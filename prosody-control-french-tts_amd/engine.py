@@ -107,7 +107,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
            "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex",
-           "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_whisper_encode_fetch",
+           "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_selftest_attention", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
 
@@ -166,6 +166,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_load.argtypes = [vp, C.POINTER(WhisperDims), vp, i64]
     lib.pce_whisper_encode_run.argtypes = [vp]
     lib.pce_selftest_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.pce_selftest_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.pce_whisper_encode_fetch.argtypes = [vp, i32, vp]
     lib.pce_profile_enable.argtypes = [vp, C.c_int]
     lib.pce_profile_reset.argtypes = [vp]
@@ -422,6 +423,22 @@ class ProsodyEngine:
                                                 out.view(torch.int16).numpy().ctypes.data))
         res = out.float().numpy()
         return res.reshape(M // rows_per_clip, N, vt_sp) if epilogue == 2 else res.reshape(M, N)
+
+    def selftest_attention(self, q, k, v, causal: bool = False, mode: int = 0):
+        """softmax(q k^T / 8) v per (clip, head) on the attention kernel; q [clips][q_len][heads*64], k / v [clips][k_len][heads*64] float
+        arrays (rounded to bf16 here).  mode 0: as the engine runs it, 1: exact path only, 2: the round-1 kernel.  Returns (out float32 decoded
+        from bf16, number of workgroups that fell back to the exact path)."""
+        import torch
+        tq, tk, tv = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).contiguous() for x in (q, k, v))
+        clips, q_len, hd = tq.shape
+        k_len = tk.shape[1]
+        assert hd % 64 == 0 and tk.shape == tv.shape == (clips, k_len, hd)
+        out = torch.zeros_like(tq)
+        fb = C.c_int32(0)
+        self._check(self._lib.pce_selftest_attention(self._ctx, tq.view(torch.int16).numpy().ctypes.data, tk.view(torch.int16).numpy().ctypes.data,
+                                                     tv.view(torch.int16).numpy().ctypes.data, clips, hd // 64, q_len, k_len, int(bool(causal)), int(mode),
+                                                     out.view(torch.int16).numpy().ctypes.data, C.addressof(fb)))
+        return out.float().numpy(), int(fb.value)
 
     def whisper_encode_fetch(self, clip: int) -> np.ndarray:
         out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)

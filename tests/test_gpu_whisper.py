@@ -420,3 +420,56 @@ def test_persistent_256_gemm_is_deterministic_and_row_count_independent(engine):
         for _ in range(3):
             assert np.array_equal(head(engine.selftest_gemm(A, B, bias, epi, 1500, 1536)), small), (N, K, epi)
         assert np.array_equal(engine.selftest_gemm(A[:M1], B, bias, epi, 1500, 1536), small)
+
+
+def _attention_reference(q, k, v, causal):
+    """torch fp32 softmax(q k^T / 8) v per (clip, head) on the bf16-rounded operands."""
+    import torch
+    tq, tk, tv = (torch.from_numpy(x).to(torch.bfloat16).float() for x in (q, k, v))
+    clips, q_len, hd = tq.shape
+    heads = hd // 64
+    tq, tk, tv = (x.view(clips, -1, heads, 64).transpose(1, 2) for x in (tq, tk, tv))
+    s = tq @ tk.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((q_len, tk.shape[2]), float("-inf")).triu(1)
+    return (s.softmax(-1) @ tv).transpose(1, 2).reshape(clips, q_len, hd).numpy()
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 1500, 1500, False), (3, 1, 77, 77, True), (2, 2, 40, 1500, False), (1, 1, 130, 65, False), (1, 1, 1, 1, True)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_attention_kernel_against_torch(engine, shape, mode):
+    """The attention kernel alone (self-test entry point): encoder shape, causal decoder prefix, decoder-over-audio cross attention,
+    ragged lengths (a key tile with one key, a query block with two queries), a single token.  Modes: the kernel as the engine runs it
+    (softmax reference fixed after the first key tile), its exact running-maximum path, and the round-1 kernel.  Tolerance: P and the
+    output are bf16 (2^-8 relative), the sums fp32: 1e-2 absolute on outputs that are convex combinations of unit-variance values."""
+    clips, heads, q_len, k_len, causal = shape
+    rng = np.random.default_rng(q_len * 7 + k_len)
+    q = rng.standard_normal((clips, q_len, heads * 64)).astype(np.float32) * 1.5
+    k = rng.standard_normal((clips, k_len, heads * 64)).astype(np.float32) * 1.5
+    v = rng.standard_normal((clips, k_len, heads * 64)).astype(np.float32)
+    got, fell_back = engine.selftest_attention(q, k, v, causal, mode)
+    want = _attention_reference(q, k, v, causal)
+    assert np.isfinite(got).all() and fell_back == 0
+    assert np.max(np.abs(got - want)) <= 1e-2, np.max(np.abs(got - want))
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 6e-3
+
+
+def test_attention_fixed_reference_overflow_takes_the_exact_path(engine):
+    """Scores that outgrow the first key tile's maximum by more than fp32's exponent range (2^127 after the log2(e)/8 scale): the fast path
+    sees a non-finite row sum, the workgroup runs again with the running maximum, and the result is the exact softmax (here: one
+    dominant key per query, so the output is that key's value row).  Moderately larger scores (2^46) must NOT fall back."""
+    rng = np.random.default_rng(5)
+    q_len = k_len = 320
+    q = rng.standard_normal((1, q_len, 64)).astype(np.float32)
+    k = rng.standard_normal((1, k_len, 64)).astype(np.float32) * 0.1
+    v = rng.standard_normal((1, k_len, 64)).astype(np.float32)
+    for boost, expect_fallback in ((10.0, False), (400.0, True)):        # the loved key scores about N(0, 8 boost): 2^46 / 2^1800 at 3 sigma
+        k2 = k.copy()
+        k2[0, 200] = np.sign(q[0].mean(axis=0)) * boost         # a key in the FOURTH tile that every query with a positive projection loves
+        got, fell_back = engine.selftest_attention(q, k2, v, False, 0)
+        want = _attention_reference(q, k2, v, False)
+        assert np.isfinite(got).all()
+        assert (fell_back > 0) == expect_fallback, (boost, fell_back)
+        assert np.max(np.abs(got - want)) <= 2e-2, (boost, np.max(np.abs(got - want)))
+        exact, _ = engine.selftest_attention(q, k2, v, False, 1)
+        assert np.max(np.abs(exact - want)) <= 2e-2
