@@ -119,6 +119,10 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
     c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
     c->attn_mode = getenv("PCE_ATTN") ? atoi(getenv("PCE_ATTN")) : 1;
+    c->gemm_sm = getenv("PCE_GEMM_SM") ? atoi(getenv("PCE_GEMM_SM")) : 0;
+    c->gemm_sn = getenv("PCE_GEMM_SN") ? atoi(getenv("PCE_GEMM_SN")) : 0;
+    c->gemm_wide = getenv("PCE_GEMM_WIDE") ? atoi(getenv("PCE_GEMM_WIDE")) : -1;
+    c->gemm_trace = getenv("PCE_GEMM_TRACE") != nullptr;
     c->dbg_pitch_lds_fft = getenv("PCE_PITCH_LDS_FFT") != nullptr;
     c->dbg_pitch_tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) : -1;
     c->dbg_pitch = getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0;

@@ -1490,8 +1490,7 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
     const int tiles_n = N / G_BN;
     int sn = 1;
     for (int cand : {8, 6, 4, 3, 2}) if (tiles_n % cand == 0) { sn = cand; break; }        // supertile width (divides the N tiles)
-    static const int sm_env = getenv("PCE_GEMM_SM") ? atoi(getenv("PCE_GEMM_SM")) : 0, sn_env = getenv("PCE_GEMM_SN") ? atoi(getenv("PCE_GEMM_SN")) : 0;
-    static const int wide_env = getenv("PCE_GEMM_WIDE") ? atoi(getenv("PCE_GEMM_WIDE")) : -1;
+    const int sm_env = c->gemm_sm, sn_env = c->gemm_sn, wide_env = c->gemm_wide;       // diagnostics, read once at pce_create
     const bool wide_ok = N % W_BN == 0 && K % W_BK == 0 && (int64_t)M * batch >= 4096 && (EPI != EPI_QKV || v_col0 % W_BN == 0);
     if (wide_ok && (wide_env > 0 || (wide_env < 0 && N >= 1536))) {      // wide outputs (QKV, fc1; from N = 1536 so that the tiny model exercises it in the tests)
         const int wt = N / W_BN;
@@ -1507,7 +1506,7 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
     int sm = sm_env > 0 ? sm_env : 16;                     // 16 x sn measured best by a hair (645-656 TFLOP/s over 4..16 x 2..8)
     if (sn_env > 0 && tiles_n % sn_env == 0) sn = sn_env;
     dim3 grid((unsigned)tiles_n, (unsigned)(div_up(M, G_BM * sm) * sm), (unsigned)batch);
-    static const bool want_trace = getenv("PCE_GEMM_TRACE") != nullptr;
+    const bool want_trace = c->gemm_trace;
     if (want_trace) {
         const size_t nblk = (size_t)grid.x * grid.y;
         (void)hipMalloc(&g_gemm_trace, nblk * 32); (void)hipMemsetAsync(g_gemm_trace, 0, nblk * 32, c->stream);
