@@ -374,6 +374,13 @@ void k_flat4(const bf16 *__restrict__ A, const bf16 *__restrict__ B, int M, int 
                     if (ABL & 16) {     // ablation: the same stores into a 128 KB window per workgroup that stays in L2
                         const int mm = blockIdx.x * 256 + hA * 128 + wr * 64 + i * 16 + fr;
                         *reinterpret_cast<bf16x8 *>(C + (int64_t)mm * 256 + hB * 128 + wc * 32 + fq * 8) = o;
+                    } else if (ABL & 32) {   // ablation: the same bytes as 8 rows x 128 B (full lines) per instruction; placement is NOT that of the product
+                        const int voff2 = ((fr & 7) * N + (fq + 4 * (fr >> 3)) * 8) * 2;
+                        const int soff2 = ((m0 + hA * 128 + wr * 64 + i * 16 + hB * 8) * N + n0 + wc * 64) * 2;
+                        if (ABL & 128) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voff2, soff2, 2);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voff2, soff2, 0);
+                    } else if (ABL & 128) {  // ablation: non-temporal stores
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voffC, soff, 2);
                     } else if (!(ABL & 8))
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, voffC, soff, 0);
                 }
@@ -421,12 +428,16 @@ void k_flat4(const bf16 *__restrict__ A, const bf16 *__restrict__ B, int M, int 
         if (!(ABL & 2)) read_B3<1, 1>(F, dsm, R, par ^ 1);                                             /* B1k1(s+1) */ \
         wait_lgkm<2>(); __builtin_amdgcn_s_setprio(1); mma8<ABL, 1, 0, 1>(acc, F); GEND                                \
         pc1 = pc2; it1 = it2; kt1 = kt2; advance(pc2, it2, kt2);                                                       \
-        if (LAST) { store_tile(c_m0, c_n0); wait_vm<22>(); } else wait_vm<6>();                                        \
+        if (LAST) { unsigned long long ts0 = 0; if (ABL & 256) ts0 = __builtin_amdgcn_s_memtime();                      \
+                    store_tile(c_m0, c_n0); if (ABL & 256) ph[4] += __builtin_amdgcn_s_memtime() - ts0; wait_vm<22>(); } else wait_vm<6>(); \
         wait_lgkm0();                                                                                                  \
         par ^= 1;                                                                                                      \
+        if (ABL & 256) { const unsigned long long tn = __builtin_amdgcn_s_memtime();                                   \
+            const int cls = (FIRST) ? 0 : (kt == 1) ? 1 : (LAST) ? 3 : 2; ph[cls] += tn - tprev; if (cls == 2) ph[5]++; tprev = tn; } \
     }
 #define GEND __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0);
     int par = 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();   // cycles in: first / second / middle / last K-steps, store issue; middle count
     for (int it = 0; it < S.my_tiles; it++) {
         for (int kt = 0; kt < nk; kt++) KSTEP4(kt == 0, kt == nk - 1)
         if (it + 1 < S.my_tiles) S.tile(it + 1, c_m0, c_n0);
@@ -434,6 +445,7 @@ void k_flat4(const bf16 *__restrict__ A, const bf16 *__restrict__ B, int M, int 
 #undef GEND
 #undef KSTEP4
     if (stamps && threadIdx.x == 0) { unsigned long long *o = stamps + 4 * blockIdx.x; o[0] = st0; o[1] = sr0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime(); }
+    if ((ABL & 256) && stamps && threadIdx.x == 0) { unsigned long long *o = stamps + 4 * 256 + 8 * blockIdx.x; for (int i = 0; i < 6; i++) o[i] = ph[i]; o[6] = (unsigned long long)S.my_tiles; }
 }
 
 template <class F> float time_ms(F f, int reps)
@@ -529,9 +541,13 @@ int main(int argc, char **argv)
     RUNP(0, 8, 0)
     check_rows("flat4");
     RUNP(0, 16, 0) RUNP(0, 16, 40000) RUNP(0, 8, 40000)
+    // (tried: the A operand three K-steps deep -- 10 slots, 160 KB, B half-tiles queued before the step's A0 so that the in-order vmcnt waits leave
+    //  the A loads outstanding: +2 % / -1 % / +4 % on the out-proj / fc1 / fc2 shapes: operand latency is not what bounds the K-steps)
+
+    RUNP(32, 8, 40000) RUNP(128, 8, 40000) RUNP(160, 8, 40000) RUNP(8, 8, 40000)
     RUNP(1, 8, 0) RUNP(14, 8, 0) RUNP(8, 8, 0) RUNP(4, 8, 0) RUNP(11, 8, 0) RUNP(16, 8, 0) RUNP(16, 8, 40000) RUNP(64, 8, 40000) RUNP(10, 8, 0) RUNP(12, 8, 0) RUNP(9, 8, 0)
     {
-        unsigned long long *stamps; CK(hipMalloc(&stamps, 256 * 32 * 2));
+        unsigned long long *stamps; CK(hipMalloc(&stamps, 256 * 32 + 256 * 64)); CK(hipMemset(stamps, 0, 256 * 32 + 256 * 64));
         auto clock_of = [&](const char *name, auto launch) {
             for (int i = 0; i < 300; i++) launch();
             CK(hipDeviceSynchronize());
@@ -545,6 +561,17 @@ int main(int argc, char **argv)
         CK(hipFuncSetAttribute((const void *)k_flat4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CK(hipFuncSetAttribute((const void *)k_flat4<14>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         CK(hipFuncSetAttribute((const void *)k_flat4<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        {   // where a workgroup's time goes (wave 0's view): K-steps by position in the tile, and the time spent ISSUING the epilogue's stores
+            CK(hipFuncSetAttribute((const void *)k_flat4<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            for (int i = 0; i < 20; i++) hipLaunchKernelGGL((k_flat4<256>), dim3(n_cu), dim3(FTHREADS), lds, 0, A, B, M, N, K, C, 8, sn, 40000, stamps);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(n_cu * 8);
+            CK(hipMemcpy(h.data(), stamps + 4 * 256, n_cu * 64, hipMemcpyDeviceToHost));
+            double a[6] = {0, 0, 0, 0, 0, 0}, tiles = 0;
+            for (int b = 0; b < n_cu; b++) { for (int i = 0; i < 6; i++) a[i] += (double)h[8 * b + i]; tiles += (double)h[8 * b + 6]; }
+            printf("per tile (cycles, mean over workgroups): first K-step %.0f, second %.0f, a middle one %.0f, last (incl. epilogue) %.0f of which store issue %.0f; tile total %.0f\n",
+                   a[0] / tiles, a[1] / tiles, a[2] / a[5], a[3] / tiles, a[4] / tiles, (a[0] + a[1] + a[2] + a[3]) / tiles);
+        }
         clock_of("flat4 full", [&] { hipLaunchKernelGGL((k_flat4<0>), dim3(n_cu), dim3(FTHREADS), lds, 0, A, B, M, N, K, C, 8, sn, 0, stamps); });
         clock_of("flat4 MFMA only", [&] { hipLaunchKernelGGL((k_flat4<14>), dim3(n_cu), dim3(FTHREADS), lds, 0, A, B, M, N, K, C, 8, sn, 0, stamps); });
         clock_of("flat4 no stores", [&] { hipLaunchKernelGGL((k_flat4<8>), dim3(n_cu), dim3(FTHREADS), lds, 0, A, B, M, N, K, C, 8, sn, 0, stamps); });
