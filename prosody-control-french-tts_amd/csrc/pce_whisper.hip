@@ -1374,6 +1374,7 @@ struct WhisperState {
     bool dec_loaded = false;
     DevBuf dw_bf16, dw_f32, d_tok_emb, d_pos_emb;
     DevBuf d_tab, d_tokens, d_resid, d_ln, d_qk, d_vt, d_attn, d_q, d_hidden, d_enc_bf16, d_aw, d_cost, d_trace, d_pi, d_pj, d_pl, d_heads;
+    int enc_bf16_clips = -1;             // d_enc_bf16 holds the bf16 copy of final_out for this many clips (written by the encoder's last LayerNorm)
     // free-running decoding: tied output projection in bf16 (rows padded to 128), cross K / V of every layer, last-position buffers
     DevBuf g_emb_bf16, g_xk, g_xvt, g_last, g_lastln, g_logits, g_mask, g_next;
     int g_xkv_clips = -1;            // clips the cross K / V cache was computed for (-1: stale)
@@ -1755,12 +1756,12 @@ int pce_whisper_encode_run(pce_ctx *c)
     // into the LayerNorm that follows (k_add_layernorm): one pass over the residual stream instead of the GEMM's read-modify-write
     // plus the LayerNorm's read.
     const bool flat = c->gemm_flat && d % F_T == 0 && M >= 2048 && (int64_t)M * 4 * d * 2 < (1ll << 32);
-    if (flat) PCE_HIP(c, w->delta.reserve(sizeof(bf16) * (size_t)M * d));
+    if (flat) { PCE_HIP(c, w->delta.reserve(sizeof(bf16) * (size_t)M * d)); PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)M * d + 4096)); }
     auto add_ln = [&](size_t w_off, size_t b_off, bool last) {
         KernelTimer kt(c, PCE_K_LAYERNORM);
         if (last)
             hipLaunchKernelGGL((k_add_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(),
-                               Wf + w_off, Wf + b_off, M, d, w->final_out.as<float>(), 1e-5f);
+                               Wf + w_off, Wf + b_off, M, d, w->final_out.as<float>(), 1e-5f, w->d_enc_bf16.as<bf16>());   // + the bf16 copy the decoder's cross K / V projections read
         else
             hipLaunchKernelGGL((k_add_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(),
                                Wf + w_off, Wf + b_off, M, d, w->ln_out.as<bf16>(), 1e-5f);
@@ -1816,7 +1817,7 @@ int pce_whisper_encode_run(pce_ctx *c)
                            Wf + w->lnp_b, M, d, w->final_out.as<float>());
     }
     PCE_HIP(c, hipGetLastError());
-    w->n_clips_enc = n; w->g_xkv_clips = -1; w->g_cache_len = -1;
+    w->n_clips_enc = n; w->g_xkv_clips = -1; w->g_cache_len = -1; w->enc_bf16_clips = flat ? n : -1;
     return PCE_OK;
 }
 
@@ -2080,8 +2081,9 @@ int pce_whisper_align_run(pce_ctx *c, const int32_t *tokens, const int32_t *toke
     const bf16 *Wb = w->dw_bf16.as<bf16>();
     const float *Wf = w->dw_f32.as<float>();
     KernelTimer timer(c, PCE_K_WHISPER_ALIGN);
-    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up(Ma * d, 256)), dim3(256), 0, c->stream, w->final_out.as<float>(),
-                       w->d_enc_bf16.as<bf16>(), Ma * d);
+    if (w->enc_bf16_clips != n)                                   // (the persistent-GEMM encoder path has already written it)
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up(Ma * d, 256)), dim3(256), 0, c->stream, w->final_out.as<float>(),
+                               w->d_enc_bf16.as<bf16>(), Ma * d);
     hipLaunchKernelGGL(k_embed_tokens, dim3((unsigned)div_up(Mt * d, 256)), dim3(256), 0, c->stream, w->d_tokens.as<int>(),
                        w->d_tok_emb.as<float>(), w->d_pos_emb.as<float>(), T_pad, w->tdims.n_text_ctx, d, Mt, w->d_resid.as<float>());
     auto attn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp,
@@ -2259,8 +2261,9 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
         PCE_HIP(c, w->g_xvt.reserve(sizeof(bf16) * xvt_l * (size_t)L + 4096));
         PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)Ma * d + 4096));
         PCE_HIP(c, hipMemsetAsync(w->g_xvt.p, 0, sizeof(bf16) * xvt_l * (size_t)L, c->stream));      // V^T columns 1500..AT_SP are read as zeros
-        hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up(Ma * d, 256)), dim3(256), 0, c->stream, w->final_out.as<float>(),
-                           w->d_enc_bf16.as<bf16>(), Ma * d);
+        if (w->enc_bf16_clips != n)
+            hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)div_up(Ma * d, 256)), dim3(256), 0, c->stream, w->final_out.as<float>(),
+                               w->d_enc_bf16.as<bf16>(), Ma * d);
         for (int l = 0; l < L; l++) {
             const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
             project_cross_kv(c, w->d_enc_bf16.as<bf16>(), (int)Ma, d, Wb + ly.xkv_w, Wf + ly.xkv_b, w->g_xk.as<bf16>() + xk_l * (size_t)l,
