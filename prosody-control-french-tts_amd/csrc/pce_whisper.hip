@@ -1269,6 +1269,20 @@ __global__ __launch_bounds__(256) void k_align_colnorm(float *__restrict__ w, co
     const int T = t_len[clip], F = f_len[clip];
     if (s >= F) return;
     float *col = w + (((int64_t)clip * n_sel + sel) * T_pad) * (int64_t)F_pad + s;
+    if (T <= 64) {                                               // the usual case (a window's tokens): the column lives in registers, one read and one write
+        float v[64];
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 64; t++) { v[t] = t < T ? __builtin_nontemporal_load(col + (int64_t)t * F_pad) : 0.f; sum += v[t]; }      // (same order of additions as the loop below)
+        const float mean = sum / (float)T;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 64; t++) if (t < T) { const float a = v[t] - mean; q += a * a; }
+        const float sd = sqrtf(q / (float)T);
+#pragma unroll
+        for (int t = 0; t < 64; t++) if (t < T) col[(int64_t)t * F_pad] = (v[t] - mean) / sd;
+        return;
+    }
     float sum = 0.f;
     for (int t = 0; t < T; t++) sum += col[(int64_t)t * F_pad];
     const float mean = sum / (float)T;
