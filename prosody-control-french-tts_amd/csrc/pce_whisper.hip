@@ -171,16 +171,49 @@ enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_GELU_POS_F32 = 2, EPI_RESID_F32 = 3,
 constexpr int AT_SP = 1536;               // padded key axis of the transposed V image (multiple of the 64-key tile)
 constexpr int G_BM = 128, G_BN = 128, G_BK = 64;
 
-// GELU(x) = x/2 (1 + erf(x/sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16
-// step of the outputs): libm's erff costs more than the tile's MFMAs in a K = 768 epilogue.
+// GELU(x) = x/2 (1 + erf(x/sqrt 2)) = x/2 + |x|/2 erf(|x|/sqrt 2) (erf is odd: no sign select); erf by Abramowitz-Stegun 7.1.26,
+// erf(z) = 1 - t P(t) exp(-z^2), t = 1/(1 + p z), |error| < 1.5e-7 -- far below the bf16 step of the outputs (libm's erff costs more than
+// the tile's MFMAs in a K = 768 epilogue).  With z' = z sqrt(log2 e) the exponential is a bare v_exp_f32 of -z'^2 and p z = (p / sqrt(log2 e)) z'.
+// gelu_exact8 is the same operation sequence on eight values, written level by level: the eight dependency chains interleave, so the packed
+// fp32 instructions the compiler forms need no wait states between them (the one-value form in a loop cost 18 issue slots per value, 4 of
+// them s_nop; this costs 11).
+constexpr float GELU_C = 0.70710678118654752440f * 1.2011224087864498f;     // |x| -> z' = |x| / sqrt 2 * sqrt(log2 e)
+constexpr float GELU_P = 0.3275911f / 1.2011224087864498f;
 __device__ __forceinline__ float gelu_exact(float x)
 {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    const float erf_x = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erf_x);
+    const float zp = fabsf(x) * GELU_C;
+    const float t = __builtin_amdgcn_rcpf(fmaf(zp, GELU_P, 1.0f));         // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
+    const float e = __builtin_amdgcn_exp2f(zp * -zp);
+    const float poly = fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-(t * poly), e, 1.0f);
+    const float h = 0.5f * x;
+    return fmaf(fabsf(h), erf_abs, h);
+}
+__device__ __forceinline__ void gelu_exact8(float (&x)[8])
+{
+    float zp[8], t[8], e[8], poly[8], h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) zp[i] = fabsf(x[i]) * GELU_C;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = __builtin_amdgcn_rcpf(fmaf(zp[i], GELU_P, 1.0f));
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = __builtin_amdgcn_exp2f(zp[i] * -zp[i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) poly[i] = fmaf(t[i], 1.061405429f, -1.453152027f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) poly[i] = fmaf(t[i], poly[i], 1.421413741f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) poly[i] = fmaf(t[i], poly[i], -0.284496736f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) poly[i] = fmaf(t[i], poly[i], 0.254829592f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) poly[i] = t[i] * poly[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = fmaf(-poly[i], e[i], 1.0f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = 0.5f * x[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = fmaf(fabsf(h[i]), e[i], h[i]);
 }
 
 // LDS image of one operand tile: 128 rows x 64 bf16 (128 B = eight 16-byte chunks per row), rows
@@ -802,14 +835,13 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs A)
 // with eight waves per workgroup (half the DMA instructions per wave): 3.0 ms.
 // ---------------------------------------------------------------------------
 template <bool EXACT>
-__device__ __forceinline__ bool attn_block(const AttnArgs &A, bf16 *smem)
+__device__ __forceinline__ bool attn_block(const AttnArgs &A, bf16 *smem, int bx, int head, int clip)
 {
     constexpr int NS = 3, DPW = 4;                               // ring slots; DMA wave-instructions per wave and tile (16 pieces of 1 KB, 4 waves)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, clip = blockIdx.z;
     const int Sq = A.q_len[clip], Sk = A.k_len[clip];
-    const int q0 = blockIdx.x * AT_QB + wv * 32;
+    const int q0 = bx * AT_QB + wv * 32;
     const bf16 *qbase = A.q + (int64_t)A.q_row0[clip] * A.q_ld + head * 64;
     const bf16 *kbase = A.k + (int64_t)A.k_row0[clip] * A.k_ld + head * 64;
     const bf16 *vtbase = A.vt + (int64_t)clip * A.vt_clip + (int64_t)head * 64 * A.vt_sp;
@@ -852,7 +884,7 @@ __device__ __forceinline__ bool attn_block(const AttnArgs &A, bf16 *smem)
     const float sl2 = 0.125f * 1.4426950408889634f;               // softmax scale * log2(e): exp(x) = exp2(x log2 e)
     const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): swap bits 2 and 3 (see k_attention)
     int k_need = Sk;
-    if (A.causal) k_need = min(Sk, (int)blockIdx.x * AT_QB + AT_QB);
+    if (A.causal) k_need = min(Sk, bx * AT_QB + AT_QB);
     const int nt = (k_need + 63) / 64;
     const int my_q = q0 + r;
     int kaddr[2][4], vaddr[2][4];                                // LDS addresses of this lane's fragments inside a slot (elements)
@@ -969,11 +1001,17 @@ __device__ __forceinline__ bool attn_block(const AttnArgs &A, bf16 *smem)
 __global__ __launch_bounds__(256, 3) void k_attention_lean(AttnArgs A, int force_exact)
 {
     __shared__ __attribute__((aligned(1024))) bf16 smem[3 * 2 * 64 * 64];               // [slot][K | V^T][64][64] = 48 KiB
-    if ((int)blockIdx.x * AT_QB >= A.q_len[blockIdx.z]) return;
-    if (!force_exact && attn_block<false>(A, smem)) return;
+    // Workgroups go to the 8 XCDs round robin by linear id, and the query blocks of one (clip, head) share its K / V^T through L2: give every XCD
+    // a CONTIGUOUS range of (clip, head, query block) triples, so that the blocks that share keys meet in one L2 instead of eight
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), xcd = lin & 7u, per = total >> 3, rem = total & 7u;
+    const unsigned logical = xcd * per + (xcd < rem ? xcd : rem) + (lin >> 3);
+    const int bx = (int)(logical % nx), head = (int)((logical / nx) % ny), clip = (int)(logical / (nx * ny));
+    if (bx * AT_QB >= A.q_len[clip]) return;
+    if (!force_exact && attn_block<false>(A, smem, bx, head, clip)) return;
     if (!force_exact && A.fell_back && threadIdx.x == 0) atomicAdd(A.fell_back, 1);
     __syncthreads();
-    attn_block<true>(A, smem);
+    attn_block<true>(A, smem, bx, head, clip);
 }
 
 static void launch_attention(pce_ctx *c, dim3 grid, const AttnArgs &a)
