@@ -90,6 +90,15 @@ __global__ __launch_bounds__(256) void k_logmel_frames(const int16_t *__restrict
     float vmax = -1e30f;
     for (int64_t fl = blockIdx.x * 4 + wv; fl < n_fr; fl += gridDim.x * 4) {
         const int64_t frame = f_begin + fl;
+        if (frame * W_HOP - W_NFFT / 2 >= len) {
+            // a frame of the zero padding behind the audio (two thirds of the 30 s window of a 10 s clip): every sample is an exact zero, so are
+            // the spectrum and the mel energies, and the value is log10 of the 1e-10 clamp -- written without running the transform
+            const float lg = log10f(fmaxf(0.f, 1e-10f));
+            for (int b = lane; b < n_mels; b += 64)
+                if (!scan) logspec[((int64_t)clip * n_mels + b) * W_FRAMES + fl] = lg;
+            vmax = fmaxf(vmax, lg);
+            continue;
+        }
         // windowed frame, centre = frame*160, reflect padding at the start, zeros past the audio
         for (int n = lane; n < W_NFFT; n += 64) {
             int64_t i = frame * W_HOP - W_NFFT / 2 + n;

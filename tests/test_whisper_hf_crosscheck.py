@@ -20,7 +20,8 @@ def test_encoder_decoder_and_cross_attention_match_transformers():
     We, Wd = WW.synthetic_weights(edims, seed=77), WW.synthetic_decoder_weights(tdims, seed=78)
     clip = synth.synth_clip(int(g["clip_index"][0]), seconds=float(g["seconds"][0]))
     mel = WO.log_mel(clip, 80)
-    assert np.max(np.abs(mel[:, g["mel_cols"]] - g["hf_mel"])) <= 1e-5             # transformers' WhisperFeatureExtractor (observed: identical)
+    # transformers' WhisperFeatureExtractor (observed: identical on the build container's CPU, 1.7e-5 on the GPU box's host: torch's CPU FFT differs by host)
+    assert np.max(np.abs(mel[:, g["mel_cols"]] - g["hf_mel"])) <= 5e-5
     enc = WO.encoder_forward(mel, We, edims)
     assert enc.shape == (1500, 128)
     assert np.max(np.abs(enc[g["rows"]] - g["enc_rows"])) <= 2e-4, float(np.max(np.abs(enc[g["rows"]] - g["enc_rows"])))
