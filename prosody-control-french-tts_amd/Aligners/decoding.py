@@ -138,7 +138,10 @@ def segments_and_seek(tokens, timestamp_begin: int, seek: int, segment_size: int
 def transcribe_tokens(engine, n_mels: int, n_vocab: int, initial_tokens, rules: dict, sample_len: int, max_windows: int = 64):
     """Greedy transcription of every clip of the engine's resident 16 kHz batch, window by window:
     log-mel window at each clip's seek position (``logmel_run_at``), encoder, ``greedy_decode``, ``segments_and_seek``.
-    -> per clip the list of segments (token ids; absolute times).  The encoder and decoder weights must be loaded."""
+    -> per clip the list of segments (token ids; absolute times).  The encoder and decoder weights must be loaded.
+    Every window starts from the same ``initial_tokens`` (no ``condition_on_previous_text``, no temperature fallback): the
+    token-level building block; ``Aligners.transcribe.transcribe_batch`` is the restatement of whisper.transcribe with those.
+    Raises ``RuntimeError`` when ``max_windows`` is exhausted with audio left (never a silently truncated transcript)."""
     lens = [int(n) for n in engine.clip_lengths]
     content = [n // 160 for n in lens]
     seeks = [0] * len(lens)
@@ -158,4 +161,7 @@ def transcribe_tokens(engine, n_mels: int, n_vocab: int, initial_tokens, rules: 
                 continue
             segs, seeks[i] = segments_and_seek(new, rules["timestamp_begin"], seeks[i], seg_size)
             out[i].extend(segs)
+    left = [i for i in range(len(lens)) if seeks[i] < content[i]]
+    if left:
+        raise RuntimeError(f"transcribe_tokens: {max_windows} windows were not enough for clips {left[:8]}; raise max_windows")
     return out
