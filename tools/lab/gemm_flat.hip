@@ -339,6 +339,18 @@ void k_flat4(const bf16 *__restrict__ A, const bf16 *__restrict__ B, int M, int 
     auto issue = [&](const Cursor &c, int kind, int par) {   // kind 0 A0, 1 B0, 2 B1, 3 A1
         if (ABL & 4) return;
         bf16 *slot = dsm + ((kind == 0 ? 0 : kind == 3 ? 1 : kind == 1 ? 2 : 3) * 2 + par) * HALF_ELEMS;
+        if (ABL & 512) {
+            // ablation: operands as if stored half-tile by half-tile ([rows / 128][K / 64][128 x 64] images, 16 KB contiguous each): every DMA
+            // instruction copies 1 KB of consecutive bytes (timing only: the data is not what the product needs)
+            const bool is_a = kind == 0 || kind == 3;
+            const unsigned row0 = (unsigned)(is_a ? c.m0 : c.n0) + ((kind == 3 || kind == 2) ? 128u : 0u);
+            const unsigned img = ((row0 >> 7) * (unsigned)(K / FK) + (unsigned)(c.kofs / FK)) * 16384u;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rsA : rsB, (__attribute__((address_space(3))) void *)(slot + (wv + 8 * i) * 8 * FK), 16,
+                                                         lane * 16, (int)(img + (unsigned)(wv + 8 * i) * 1024u), 0, 0);
+            return;
+        }
         if (kind == 0) issue_half_buf(rsA, voffA, (c.m0 * K + c.kofs) * 2, ld2_64, slot, wv);
         else if (kind == 3) issue_half_buf(rsA, voffA, ((c.m0 + 128) * K + c.kofs) * 2, ld2_64, slot, wv);
         else if (kind == 1) issue_half_buf(rsB, voffB, (c.n0 * K + c.kofs) * 2, ld2_64, slot, wv);
@@ -544,7 +556,7 @@ int main(int argc, char **argv)
     // (tried: the A operand three K-steps deep -- 10 slots, 160 KB, B half-tiles queued before the step's A0 so that the in-order vmcnt waits leave
     //  the A loads outstanding: +2 % / -1 % / +4 % on the out-proj / fc1 / fc2 shapes: operand latency is not what bounds the K-steps)
 
-    RUNP(32, 8, 40000) RUNP(128, 8, 40000) RUNP(160, 8, 40000) RUNP(8, 8, 40000)
+    RUNP(32, 8, 40000) RUNP(128, 8, 40000) RUNP(160, 8, 40000) RUNP(8, 8, 40000) RUNP(512, 8, 40000) RUNP(512, 8, 0) RUNP(520, 8, 40000)
     RUNP(1, 8, 0) RUNP(14, 8, 0) RUNP(8, 8, 0) RUNP(4, 8, 0) RUNP(11, 8, 0) RUNP(16, 8, 0) RUNP(16, 8, 40000) RUNP(64, 8, 40000) RUNP(10, 8, 0) RUNP(12, 8, 0) RUNP(9, 8, 0)
     {
         unsigned long long *stamps; CK(hipMalloc(&stamps, 256 * 32 + 256 * 64)); CK(hipMemset(stamps, 0, 256 * 32 + 256 * 64));
