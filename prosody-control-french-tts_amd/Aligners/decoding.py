@@ -141,7 +141,7 @@ def transcribe_tokens(engine, n_mels: int, n_vocab: int, initial_tokens, rules: 
     -> per clip the list of segments (token ids; absolute times).  The encoder and decoder weights must be loaded.
     Every window starts from the same ``initial_tokens`` (no ``condition_on_previous_text``, no temperature fallback): the
     token-level building block; ``Aligners.transcribe.transcribe_batch`` is the restatement of whisper.transcribe with those.
-    Raises ``RuntimeError`` when ``max_windows`` is exhausted with audio left (never a silently truncated transcript)."""
+    Warns (``RuntimeWarning``) when ``max_windows`` is exhausted with audio left: never a silently truncated transcript."""
     lens = [int(n) for n in engine.clip_lengths]
     content = [n // 160 for n in lens]
     seeks = [0] * len(lens)
@@ -163,5 +163,6 @@ def transcribe_tokens(engine, n_mels: int, n_vocab: int, initial_tokens, rules: 
             out[i].extend(segs)
     left = [i for i in range(len(lens)) if seeks[i] < content[i]]
     if left:
-        raise RuntimeError(f"transcribe_tokens: {max_windows} windows were not enough for clips {left[:8]}; raise max_windows")
+        import warnings
+        warnings.warn(f"transcribe_tokens: stopped after {max_windows} windows with audio left in clips {left[:8]} (raise max_windows)", RuntimeWarning)
     return out
