@@ -1,7 +1,6 @@
 """Device time of k_frame_energy on the C2 batch (256 x 10 s, 16 kHz): HIP events via the engine's profiler."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import prosody_control_french_tts_amd as pkg
 from prosody_control_french_tts_amd import synth
 

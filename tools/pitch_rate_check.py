@@ -1,6 +1,5 @@
 """Time the pitch analysis at another sample rate / floor (which selects the FFT path: see k_pitch_frames MODE)."""
 import sys, time; sys.path.insert(0, '.')
-import numpy as np
 import prosody_control_french_tts_amd as P
 from prosody_control_french_tts_amd import synth
 rate = int(sys.argv[1]) if len(sys.argv) > 1 else 44100
