@@ -1536,7 +1536,10 @@ bool launch_gemm_flat(pce_ctx *c, const bf16 *A, const bf16 *B, const float *bia
     P.sm = 16; P.stagger = 20000;
     const int lds = F_RING_BYTES + N * (int)sizeof(float);
     static bool attr_done[3] = {false, false, false};
-    if (!attr_done[EPI]) { (void)hipFuncSetAttribute((const void *)k_gemm_flat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds > 147456 ? lds : 147456); attr_done[EPI] = true; }
+    if (!attr_done[EPI]) {                                   // once per epilogue: the ring + the widest bias vector the shape test above admits (N <= 6144)
+        (void)hipFuncSetAttribute((const void *)k_gemm_flat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F_RING_BYTES + 6144 * (int)sizeof(float));
+        attr_done[EPI] = true;
+    }
     const int grid = ((c->cu_count > 0 ? c->cu_count : 256) / 8) * 8;
     KernelTimer kt(c, PCE_K_GEMM_FLAT, nullptr, 2.0 * M * (double)N * K);
     hipLaunchKernelGGL((k_gemm_flat<EPI>), dim3((unsigned)grid), dim3(F_THREADS), lds, c->stream, P);

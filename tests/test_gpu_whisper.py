@@ -377,7 +377,8 @@ def test_c3_batch_of_256_is_clip_independent(engine):
         assert paths_all[i]["text_indices"][-1] == len(toks[i]) - 3 - 2 and paths_all[i]["time_indices"][-1] == frames[i] // 2 - 1
 
 
-@pytest.mark.parametrize("shape", [(3000, 1536, 768, 0), (3000, 3072, 768, 1), (6000, 768, 3072, 0), (3000, 768, 768, 2), (4100, 256, 64, 0)])
+@pytest.mark.parametrize("shape", [(3000, 1536, 768, 0), (3000, 3072, 768, 1), (6000, 768, 3072, 0), (3000, 768, 768, 2), (4100, 256, 64, 0),
+                                   (2100, 5120, 128, 0)])             # (the widest bias vector after narrower launches: Whisper-large fc1)
 def test_persistent_256_gemm_against_torch(engine, shape):
     """The persistent 256 x 256 GEMM of the big encoder projections (pce_gemm256.inc) alone, through its self-test entry
     point: C = epilogue(A B^T + bias) against torch fp32 on the bf16-rounded operands.  Tolerance: the bf16 rounding of
