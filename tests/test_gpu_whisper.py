@@ -40,7 +40,9 @@ def test_mel_filterbank_known_values():
 @pytest.mark.parametrize("dims", [dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2), WW.DIMS["tiny"],
                                   # the widths of "small" (BASELINE C3) and "medium" (the reference's default, config.yaml:15),
                                   # two layers each: the 128 x 256 GEMM with the fused QKV / V-transpose epilogue only runs at these
-                                  dict(WW.DIMS["small"], n_layer=2), dict(WW.DIMS["medium"], n_layer=2)])
+                                  dict(WW.DIMS["small"], n_layer=2), dict(WW.DIMS["medium"], n_layer=2),
+                                  # 512 and 1280: the other widths the persistent 256 x 256 GEMM takes (2 / 5 column tiles per projection)
+                                  dict(WW.DIMS["base"], n_layer=2), dict(n_mels=80, n_ctx=1500, n_state=1280, n_head=20, n_layer=1)])
 def test_encoder_matches_torch(engine, clips, dims):
     W = WW.synthetic_weights(dims)
     engine.upload(clips[:2], 16000)
