@@ -1452,7 +1452,7 @@ struct WhisperState {
     std::vector<int> al_rows, al_cols;
     MelTables mt{};
     int mel_nmels = 0;
-    int32_t n_clips_mel = -1, n_clips_enc = -1;
+    int32_t n_clips_mel = -1, n_clips_enc = -1, enc_tab_clips = -1;
     // break-prediction token classifier (BertForTokenClassification)
     struct Bert {
         pce_bert_dims dims{};
@@ -1800,12 +1800,14 @@ int pce_whisper_encode_run(pce_ctx *c)
     PCE_HIP(c, w->final_out.reserve(sizeof(float) * (size_t)M * d));
     const bf16 *Wb = w->w_bf16.as<bf16>();
     const float *Wf = w->w_f32.as<float>();
-    {   // per-clip row tables of the attention descriptor: clip c owns rows [1500 c, 1500 c + 1500)
+    if (w->enc_tab_clips != n) {   // per-clip row tables of the attention descriptor: clip c owns rows [1500 c, 1500 c + 1500); they only depend on the
+                                   // batch size, so a steady stream of equal batches uploads (and waits for) them once
         std::vector<int> tab((size_t)2 * n);
         for (int i = 0; i < n; i++) { tab[(size_t)i] = i * W_CTX; tab[(size_t)n + i] = W_CTX; }
         PCE_HIP(c, w->enc_tab.reserve(sizeof(int) * tab.size()));
         PCE_HIP(c, hipMemcpyAsync(w->enc_tab.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
         PCE_HIP(c, hipStreamSynchronize(c->stream));
+        w->enc_tab_clips = n;
     }
     KernelTimer t(c, PCE_K_WHISPER_ENC);
     PCE_HIP(c, hipMemsetAsync(w->c1_out.p, 0, sizeof(bf16) * c1_elems, c->stream));
