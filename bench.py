@@ -34,18 +34,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (never the 2:1-sparsity figure)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s fp32 vector rate (AMD's MI355X fp64 vector figure; the guide has no fp64 row)
 VALU_F64_PEAK_TFLOPS = 78.6     # fp64 vector peak (79 TF/s)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
-COMPOSITE = ("whisper_encoder", "whisper_align", "bert_forward", "whisper_decode_step")   # brackets around several launches
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+COMPOSITE = ("whisper_encoder", "whisper_align", "bert_forward", "whisper_decode_step", "whisper_decode_loop")   # brackets around several launches
 
 
 def load_pmc_traffic(workload):
     """HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 for the gfx950 wide-read
     under-count + WRITE_SIZE, KB -> B; tools/pmc_traffic.py), committed under profiles/."""
-    try:
-        with open(os.path.join(PROFILE_DIR, f"pmc_traffic_{workload}.json")) as f:
-            return json.load(f)["bytes_per_launch"]
-    except Exception:
-        return None
+    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r02")):        # (the previous round's passes until this round's are committed)
+        try:
+            with open(os.path.join(d, f"pmc_traffic_{workload}.json")) as f:
+                out = json.load(f)["bytes_per_launch"]
+            out["_source"] = os.path.relpath(os.path.join(d, f"pmc_traffic_{workload}.json"), ROOT)
+            return out
+        except Exception:
+            continue
+    return None
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -396,6 +400,25 @@ def run_rank(args, world, rank, local_rank):
             if name in COMPOSITE:
                 k["composite"] = True                                # a bracket around several launches, not a kernel
             kernels.append(k)
+        # "k_gemm_flat:<shape>" = the launches of ONE device kernel (rocprofv3 prints k_gemm_flat<EPI>) bracketed per encoder shape:
+        # they stay in `gemm_shapes`, and their sum is the `k_gemm_flat` entry the roofline is taken from
+        shapes = [k for k in kernels if ":" in k["kernel"]]
+        kernels = [k for k in kernels if ":" not in k["kernel"]]
+        gemm_shapes = []
+        if shapes:
+            base = next((k for k in kernels if k["kernel"] == "k_gemm_flat"), None)
+            tot_ms = sum(k["ms_per_step"] for k in shapes) + (base["ms_per_step"] if base else 0.0)
+            tot_n = sum(k["launches_per_step"] for k in shapes) + (base["launches_per_step"] if base else 0.0)
+            tot_fl = sum(k.get("flops_per_launch", 0.0) * k["launches_per_step"] for k in shapes) + \
+                (base.get("flops_per_launch", 0.0) * base["launches_per_step"] if base else 0.0)
+            if base:
+                kernels.remove(base)
+            kernels.append({"kernel": "k_gemm_flat", "avg_ms": tot_ms / tot_n, "launches_per_step": tot_n, "ms_per_step": tot_ms,
+                            "flops_per_launch": tot_fl / tot_n, "achieved_tflops": tot_fl / (tot_ms * 1e-3) / 1e12})
+            for k in shapes:
+                gemm_shapes.append({"shape": k["kernel"].split(":", 1)[1], "avg_ms": k["avg_ms"], "launches_per_step": k["launches_per_step"],
+                                    "ms_per_step": k["ms_per_step"], "achieved_tflops": k.get("achieved_tflops"),
+                                    "frac": (k.get("achieved_tflops") or 0.0) / MFMA_BF16_PEAK_TFLOPS})
         kernels.sort(key=lambda k: -k["ms_per_step"])
         kt = {k["kernel"]: k for k in kernels}
         # stages: a stage's algorithmic bytes are moved ONCE by its kernels together; the
@@ -408,13 +431,13 @@ def run_rank(args, world, rank, local_rank):
             ("lufs (R4)", ["k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate"], pcm, None),
             ("f0 (R1: Praat AC + path + median)", ["k_pitch_frames", "k_pitch_refine", "k_pitch_delta", "k_pitch_path", "k_pitch_median"],
              pcm + f0_out, None),
-            ("stft-dB (R10)", ["k_stft_max", "k_stft_db", "k_stft_norm"], pcm + stft_out, None),
+            ("stft-dB (R10)", ["k_stft_raw", "k_stft_norm", "k_stft_max", "k_stft_db"], pcm + stft_out, None),     # default form: raw + norm; PCE_STFT_TWO_FFT: max + db
         ]
         if wdims:
             d, L = wdims["n_state"], wdims["n_layer"]
             flop = args.clips * (2.0 * 3000 * d * 240 + 2.0 * 1500 * d * 3 * d
                                  + L * (2.0 * 1500 * d * 3 * d + 4.0 * 1500 * 1500 * d + 2.0 * 1500 * d * d + 16.0 * 1500 * d * d))
-            stages += [("log-mel (R8)", ["k_logmel"], pcm + 80 * 3000 * 4.0 * args.clips, None),
+            stages += [("log-mel (R8)", ["k_logmel_frames", "k_logmel_norm"], pcm + 80 * 3000 * 4.0 * args.clips, None),
                        (f"whisper-{args.whisper_model} encoder (R8)", ["whisper_encoder"], None, flop)]
             # (the forced-alignment leg -- decoder over 24-48 tokens per clip, alignment heads, DTW -- is timed as `whisper_align` in `kernels`)
         kernel_stage_bytes = {}
@@ -468,6 +491,11 @@ def run_rank(args, world, rank, local_rank):
                             "note": "dominant kernel by device time per step; achieved = the algorithmic bytes of its stage (SURVEY.md 8d: "
                                     "PCM in + results out, intermediates excluded) / this kernel's own mean launch duration.  The F0 kernels are "
                                     "fp64-VALU bound (about 1e3 flop per algorithmic byte): their HBM fraction is small by construction"}
+        floor = None
+        if wdims:
+            floor_ms = flop / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
+            floor = {"encoder_flops": flop, "mfma_floor_ms": floor_ms, "step_frac_of_mfma_floor": floor_ms / (dt / args.steps * 1e3),
+                     "note": "encoder FLOPs of the step at the dense bf16 peak / the measured step (the alignment leg's and the prosody leg's work is not in the numerator)"}
         info = eng.device_info()
         what = ("energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256"
                 + (f" + log-mel + Whisper-{args.whisper_model} encoder + teacher-forced decoder / cross-attention DTW alignment "
@@ -482,7 +510,7 @@ def run_rank(args, world, rank, local_rank):
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, " + what,
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)"},
-            "roofline": roofline, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
+            "roofline": roofline, "mfma_floor": floor, "gemm_shapes": gemm_shapes, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
             "streamed_value": streamed, "device": info["name"], "host_cores": os.cpu_count(),
         }))
     eng.close()

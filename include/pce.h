@@ -360,7 +360,12 @@ enum pce_kernel_id {
     PCE_K_FRAME_ENERGY, PCE_K_BERT, PCE_K_PYIN_FRAMES, PCE_K_PYIN_VITERBI, PCE_K_WHISPER_DECODE,
     /* the launches inside the composite entries above (whisper_encoder, whisper_align, bert_forward, whisper_decode_step),
      * each bracketed on its own so that a roofline figure divides one kernel's work by that kernel's own duration */
-    PCE_K_GEMM128, PCE_K_GEMM_WIDE, PCE_K_ATTENTION, PCE_K_LAYERNORM, PCE_K_GEMM_FLAT, PCE_K_COUNT
+    PCE_K_GEMM128, PCE_K_GEMM_WIDE, PCE_K_ATTENTION, PCE_K_LAYERNORM, PCE_K_GEMM_FLAT,
+    /* round 3: one id per device kernel name (what rocprofv3 --kernel-trace prints), and the persistent GEMM per encoder shape
+     * ("k_gemm_flat:<shape>"; PCE_K_GEMM_FLAT keeps the launches no shape is named for) */
+    PCE_K_ADD_LAYERNORM, PCE_K_STFT_RAW, PCE_K_LOGMEL_NORM, PCE_K_ATTENTION_LEAN,
+    PCE_K_GEMM_FLAT_QKV, PCE_K_GEMM_FLAT_OUT, PCE_K_GEMM_FLAT_FC1, PCE_K_GEMM_FLAT_FC2, PCE_K_GEMM_FLAT_XKV,
+    PCE_K_DECODE_LOOP, PCE_K_CROSS_ATTN1, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

@@ -85,6 +85,41 @@ def pad_vocab(dec: Dict[str, np.ndarray], tdims: dict, n_vocab: int):
         raise ValueError(f"the checkpoint embeds {tdims['n_vocab']} tokens, the vocabulary has {n_vocab}")
 
 
+# Cross-attention heads whisper.load_model installs as ``model.alignment_heads`` (openai-whisper ``__init__.py``
+# ``_ALIGNMENT_HEADS``; the ``.pt`` file does not carry them) and whisper_timestamped reads for its DTW.  openai-whisper ships
+# them as base85 bit masks; these are the same sets as [layer, head] pairs, the form the models' published
+# ``generation_config.json`` uses.  Third party, absent here: restated from those published lists, unverifiable offline --
+# a sidecar ``<size>.json`` always wins.
+ALIGNMENT_HEADS = {
+    "tiny.en": [[1, 0], [2, 0], [2, 5], [3, 0], [3, 1], [3, 2], [3, 3], [3, 4]],
+    "tiny": [[2, 2], [3, 0], [3, 2], [3, 3], [3, 4], [3, 5]],
+    "base.en": [[3, 3], [4, 7], [5, 1], [5, 5], [5, 7]],
+    "base": [[3, 1], [4, 2], [4, 3], [4, 7], [5, 1], [5, 2], [5, 4], [5, 6]],
+    "small.en": [[6, 6], [7, 0], [7, 3], [7, 8], [8, 2], [8, 5], [8, 7], [9, 0], [9, 4], [9, 8], [9, 10], [10, 0], [10, 1], [10, 2],
+                 [10, 3], [10, 6], [10, 11], [11, 2], [11, 4]],
+    "small": [[5, 3], [5, 9], [8, 0], [8, 4], [8, 7], [8, 8], [9, 0], [9, 7], [9, 9], [10, 5]],
+    "medium.en": [[11, 4], [14, 1], [14, 12], [14, 14], [15, 4], [16, 0], [16, 4], [16, 9], [17, 12], [17, 14], [18, 7], [18, 10],
+                  [18, 15], [20, 0], [20, 3], [20, 9], [20, 14], [21, 12]],
+    "medium": [[13, 15], [15, 4], [15, 15], [16, 1], [20, 0], [23, 4]],
+    "large-v1": [[9, 19], [11, 2], [11, 4], [11, 17], [22, 7], [22, 11], [22, 17], [23, 2], [23, 15]],
+    "large-v2": [[10, 12], [13, 17], [16, 11], [16, 12], [16, 13], [17, 15], [17, 16], [18, 4], [18, 11], [18, 19], [19, 11],
+                 [21, 2], [21, 3], [22, 3], [22, 9], [22, 12], [23, 5], [23, 7], [23, 13], [25, 5], [26, 1], [26, 12], [27, 15]],
+    "large-v3": [[7, 0], [10, 17], [12, 18], [13, 12], [16, 1], [17, 14], [19, 11], [21, 4], [24, 1], [25, 6]],
+    "large-v3-turbo": [[2, 4], [2, 11], [3, 3], [3, 6], [3, 11], [3, 14]],
+}
+ALIGNMENT_HEADS["large"] = ALIGNMENT_HEADS["large-v3"]          # openai-whisper 20240930: "large" -> large-v3, "turbo" -> large-v3-turbo
+ALIGNMENT_HEADS["turbo"] = ALIGNMENT_HEADS["large-v3-turbo"]
+
+
+def builtin_alignment_heads(model_size: str, n_layer: int, n_head: int):
+    """The table entry for ``model_size`` if it fits a decoder of ``n_layer`` x ``n_head`` (a miniature test model saved
+    under an official name does not), else None."""
+    heads = ALIGNMENT_HEADS.get(str(model_size).lower())
+    if heads is None or any(l >= n_layer or h >= n_head for l, h in heads):
+        return None
+    return heads
+
+
 class WhisperModel:
     """What ``whisper.load_model`` returns, reduced to what the engine needs: dims, packed weights, alignment heads."""
 
@@ -146,6 +181,14 @@ def load_model(model_size: str, model_dir: Optional[str] = None) -> WhisperModel
         with open(side, encoding="utf-8") as f:
             heads = json.load(f).get("alignment_heads")
     enc, dec = split_state_dict(sd)
+    if heads is None:
+        _, tdims = dims_from_tensors(enc, dec)
+        heads = builtin_alignment_heads(model_size, tdims["n_layer"], tdims["n_head"])
+        if heads is None:
+            import logging
+            logging.getLogger(__name__).warning(
+                "no alignment heads known for Whisper model %r (no %s, not an official size): falling back to every head of the last "
+                "half of the decoder layers; word timestamps will differ from whisper.load_model's", model_size, os.path.basename(side))
     return WhisperModel(enc, dec, heads, name=model_size)
 
 

@@ -20,7 +20,8 @@ in tests/test_aligner_host.py, GPU flow in tests/test_gpu_aligner.py):
     = exp(mean log-probability of the word's tokens), times rounded to 10 ms, words clamped into their segment when
     ``trust_whisper_timestamps``.  NOT restated: its own variant of the attention post-processing (what runs is
     openai-whisper's recipe on the same cross-attention logits) and the ``[*]`` disfluency marks (``detect_disfluencies``
-    is accepted and produces none; everything downstream handles the mark: json_to_textgrid, clean_text).
+    is accepted WITH A WARNING on every call and produces none; everything downstream handles the mark: json_to_textgrid,
+    clean_text).
 """
 from __future__ import annotations
 
@@ -183,7 +184,10 @@ def transcribe_batch(engine, model, tokenizer, clips: Sequence[np.ndarray], opti
     n = len(clips)
     clips = [np.ascontiguousarray(c, dtype=np.int16).reshape(-1) for c in clips]
     if opt.detect_disfluencies:
-        log.debug("detect_disfluencies: no [*] marks are produced by this engine (see Aligners/transcribe.py)")
+        # the one option of the reference's call (use_whisper_timestamped.py:154) this engine cannot honour: say so, loudly, every call
+        log.warning('detect_disfluencies=True: this engine produces no "[*]" disfluency marks (whisper-timestamped\'s rule is not restated: '
+                    "its source is absent); a hesitation the model did not transcribe stays inside the neighbouring words' intervals "
+                    "instead of becoming a gap interval in the TextGrid")
     # ---- 1. VAD
     cuts: List[Optional[SpeechCuts]] = [None] * n
     if opt.vad:

@@ -345,8 +345,11 @@ const char *pce_kernel_name(int id)
     static const char *names[PCE_K_COUNT] = {
         "k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
         "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta",
-        "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
-        "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat"};
+        "k_stft_max", "k_stft_db", "k_logmel_frames", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
+        "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat",
+        "k_add_layernorm", "k_stft_raw", "k_logmel_norm", "k_attention_lean",
+        "k_gemm_flat:qkv", "k_gemm_flat:out", "k_gemm_flat:fc1", "k_gemm_flat:fc2", "k_gemm_flat:xkv",
+        "whisper_decode_loop", "k_cross_attn1"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -397,7 +397,7 @@ int pce_stft_db_run(pce_ctx *c, int32_t n_fft, int32_t hop)
         }
     } else {
         {
-            KernelTimer t(c, PCE_K_STFT_DB);
+            KernelTimer t(c, PCE_K_STFT_RAW);
             hipLaunchKernelGGL((k_stft_raw<F, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, c->d_pcm, c->st_off.as<StClip>(),
                                c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>(),
                                1e-10f, c->st_out.as<float>());

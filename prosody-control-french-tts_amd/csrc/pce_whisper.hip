@@ -30,6 +30,7 @@
 #include "pce_internal.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -987,7 +988,9 @@ __device__ __forceinline__ bool attn_block(const AttnArgs &A, bf16 *smem, int bx
         }
     }
     if (!EXACT) l_run = __shfl(osum[0], r, 64);                  // row 0 of the row-sum product sits in register 0 of the lower lane half
-    const bool ok = EXACT || (l_run > 0.f && l_run < 3.0e38f) || my_q >= Sq;
+    // (the accumulators are sums of p * v, up to l_run * max|v|: a row sum near FLT_MAX can pass a bare finiteness test while O has
+    // already overflowed, so the fast path keeps eight decades of headroom; any finite reference is equally exact, the bound costs nothing)
+    const bool ok = EXACT || (l_run > 0.f && l_run < 1.0e30f) || my_q >= Sq;
     if (!EXACT && __syncthreads_or(!ok)) return false;           // some row overflowed its fixed reference: the workgroup runs again, exactly
     // O^T[d][q]: this lane owns query q0 + r; d = 32 t + (e & 3) + 8 (e >> 2) + 4 h -> runs of 4 consecutive d
     if (my_q < Sq) {
@@ -1023,10 +1026,16 @@ __global__ __launch_bounds__(256, 3) void k_attention_lean(AttnArgs A, int force
     attn_block<true>(A, smem, bx, head, clip);
 }
 
-static void launch_attention(pce_ctx *c, dim3 grid, const AttnArgs &a)
+static void launch_attention(pce_ctx *c, dim3 grid, const AttnArgs &a, double flops = 0.0)
 {
-    if (c->attn_mode == 0) hipLaunchKernelGGL(k_attention, grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_attention_lean, grid, dim3(256), 0, c->stream, a, c->attn_mode == 2 ? 1 : 0);
+    // flops > 0: a launch the profiler brackets on its own (the encoder's); the decoder's small launches stay inside their composite entry
+    if (c->attn_mode == 0) {
+        KernelTimer kt(c, PCE_K_ATTENTION, nullptr, flops);
+        hipLaunchKernelGGL(k_attention, grid, dim3(256), 0, c->stream, a);
+    } else {
+        KernelTimer kt(c, PCE_K_ATTENTION_LEAN, nullptr, flops);
+        hipLaunchKernelGGL(k_attention_lean, grid, dim3(256), 0, c->stream, a, c->attn_mode == 2 ? 1 : 0);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1091,7 +1100,8 @@ __device__ __forceinline__ float dec_uniform(unsigned seed_lo, unsigned seed_hi,
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-    return ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    // 23 random bits + 1/2: every value is exact in float and lies strictly inside (0, 1) (24 bits + 1/2 rounds to 1.0 at the top)
+    return ((float)(unsigned)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);
 }
 __global__ __launch_bounds__(256) void k_decode_rules(float *__restrict__ logits, const int *__restrict__ tokens, const int *__restrict__ t_len,
                                                      int T_pad, const unsigned char *__restrict__ vmask, DecRules R, const int *__restrict__ sample_begin_of,
@@ -1428,7 +1438,7 @@ struct WhisperState {
     pce_whisper_dims dims{};
     bool loaded = false;
     DevBuf tables, logspec, clipmax, mel_tm, mel_start, w_bf16, w_f32, pos;
-    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab, delta;
+    DevBuf c1_out, resid, ln_out, qkv, vt, attn, hidden, final_out, enc_tab, delta, delta2;
     size_t vt_elems_zeroed = 0;
     // text decoder
     pce_whisper_text_dims tdims{};
@@ -1520,28 +1530,44 @@ int mel_setup(pce_ctx *c, WhisperState *w, int n_mels)
     return PCE_OK;
 }
 
+// Does every byte offset k_gemm_flat forms stay below 2^32?  rows_pad = the rows its padded tile list reaches.
+static bool gemm_flat_offsets_fit(int64_t M, int64_t N, int64_t K, int64_t ldc, int64_t S, int64_t vt_sp)
+{
+    const int64_t tiles_m = (M + F_T - 1) / F_T, rows_pad = ((tiles_m + 15) / 16) * 16 * F_T, lim = 1ll << 32;
+    if (rows_pad * K * 2 >= lim || N * K * 2 >= lim) return false;
+    if (S > 0) return (rows_pad / S + 2) * N * vt_sp * 2 < lim;           // V^T image: one clip block per S rows (+ the clip a tile may spill into)
+    return rows_pad * ldc * 2 < lim;
+}
+
 // Persistent 256 x 256 GEMM (pce_gemm256.inc) for the big projections: A dense [M][K], C bf16.  Returns false when the shape does not fit
 // (the caller then takes the tiled kernels).
 template <int EPI>
-bool launch_gemm_flat(pce_ctx *c, const bf16 *A, const bf16 *B, const float *bias, bf16 *C, int M, int N, int K, int ldc, int S = 1, int vt_sp = 0)
+bool launch_gemm_flat(pce_ctx *c, const bf16 *A, const bf16 *B, const float *bias, bf16 *C, int M, int N, int K, int ldc, int S = 1, int vt_sp = 0,
+                      int prof_id = PCE_K_GEMM_FLAT, bf16 *C2 = nullptr, int vt_n0 = 0)
 {
-    if (!c->gemm_flat || N % F_T || K % F_K || M < 2048 || (int64_t)M * K * 2 >= (1ll << 32) || (int64_t)N * K * 2 >= (1ll << 32) ||
-        (int64_t)M * (EPI == FEPI_VT ? 1 : ldc) * 2 >= (1ll << 32) || N > 6144 || (EPI == FEPI_VT && (S % 4 || S < F_T)))
-        return false;
+    // 32-bit byte offsets: the kernel addresses the row tiles up to the PADDED tile count (16 row tiles per supertile); rows past M must
+    // fall outside the buffer resources (loads read zeros, stores are dropped), which only holds while their offsets do not wrap
+    constexpr bool HAS_VT = EPI == FEPI_VT || EPI == FEPI_SPLIT, HAS_RM = EPI != FEPI_VT;
+    if (!c->gemm_flat || N % F_T || K % F_K || M < 2048 || N > 6144 || (HAS_VT && (S % 4 || S < F_T))) return false;
+    if (EPI == FEPI_SPLIT && (!C2 || vt_n0 <= 0 || vt_n0 >= N || vt_n0 % F_T)) return false;
+    if (HAS_RM && !gemm_flat_offsets_fit(M, N, K, ldc, 0, 0)) return false;
+    if (HAS_VT && !gemm_flat_offsets_fit(M, N - vt_n0, K, 0, S, vt_sp)) return false;
     FArgs P{};
-    P.A = A; P.B = B; P.bias = bias; P.C = C; P.M = M; P.N = N; P.K = K; P.ldc = ldc; P.S = S; P.vt_sp = vt_sp;
+    P.A = A; P.B = B; P.bias = bias; P.C = C; P.M = M; P.N = N; P.K = K; P.ldc = ldc; P.S = S; P.vt_sp = vt_sp; P.C2 = C2; P.vt_n0 = vt_n0;
     const int tiles_n = N / F_T;
     P.sn = 1;
     for (int cand : {4, 3, 2}) if (tiles_n % cand == 0) { P.sn = cand; break; }
     P.sm = 16; P.stagger = 20000;
     const int lds = F_RING_BYTES + N * (int)sizeof(float);
-    static bool attr_done[3] = {false, false, false};
-    if (!attr_done[EPI]) {                                   // once per epilogue: the ring + the widest bias vector the shape test above admits (N <= 6144)
-        (void)hipFuncSetAttribute((const void *)k_gemm_flat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F_RING_BYTES + 6144 * (int)sizeof(float));
-        attr_done[EPI] = true;
+    if (!c->gemm_flat_attr[EPI]) {                           // once per context (the attribute is per device) and epilogue: the ring + the widest bias vector the shape test admits
+        if (hipFuncSetAttribute((const void *)k_gemm_flat<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F_RING_BYTES + 6144 * (int)sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        c->gemm_flat_attr[EPI] = true;
     }
     const int grid = ((c->cu_count > 0 ? c->cu_count : 256) / 8) * 8;
-    KernelTimer kt(c, PCE_K_GEMM_FLAT, nullptr, 2.0 * M * (double)N * K);
+    KernelTimer kt(c, prof_id, nullptr, 2.0 * M * (double)N * K);
     hipLaunchKernelGGL((k_gemm_flat<EPI>), dim3((unsigned)grid), dim3(F_THREADS), lds, c->stream, P);
     return true;
 }
@@ -1606,7 +1632,7 @@ void pce_whisper_free(pce_ctx *c)
     if (!c->whisper) return;
     WhisperState *w = static_cast<WhisperState *>(c->whisper);
     DevBuf *bufs[] = {&w->tables, &w->logspec, &w->clipmax, &w->mel_tm, &w->mel_start, &w->w_bf16, &w->w_f32, &w->pos, &w->c1_out, &w->resid,
-                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->delta, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
+                      &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->delta, &w->delta2, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
                       &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
                       &w->g_sk, &w->g_svt, &w->g_c_resid, &w->g_c_ln, &w->g_c_qkv, &w->g_c_attn, &w->g_c_q, &w->g_c_hidden, &w->g_c_tab,
@@ -1666,6 +1692,9 @@ static int logmel_run_impl(pce_ctx *c, int32_t n_mels, const int64_t *start_fram
         KernelTimer t(c, PCE_K_LOGMEL);
         hipLaunchKernelGGL(k_logmel_frames, dim3(W_FRAMES / 4 / 5, (unsigned)n), dim3(256), 0, c->stream, c->d_pcm,
                            c->d_clip_off.as<int64_t>(), (int)n_mels, w->mt, w->logspec.as<float>(), w->clipmax.as<unsigned int>(), d_start, 0);
+    }
+    {
+        KernelTimer t(c, PCE_K_LOGMEL_NORM);
         hipLaunchKernelGGL(k_logmel_norm, dim3(div_up(W_FRAMES, 64), div_up(n_mels, 64), (unsigned)n), dim3(256), 0, c->stream,
                            w->logspec.as<float>(), w->clipmax.as<unsigned int>(), (int)n_mels, w->mel_tm.as<bf16>());
     }
@@ -1821,16 +1850,23 @@ int pce_whisper_encode_run(pce_ctx *c)
     // clips).  On that path a branch (attention projection, MLP) leaves its output as a bf16 row block and the residual add is fused
     // into the LayerNorm that follows (k_add_layernorm): one pass over the residual stream instead of the GEMM's read-modify-write
     // plus the LayerNorm's read.
-    const bool flat = c->gemm_flat && d % F_T == 0 && M >= 2048 && (int64_t)M * 4 * d * 2 < (1ll << 32);
-    if (flat) { PCE_HIP(c, w->delta.reserve(sizeof(bf16) * (size_t)M * d)); PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)M * d + 4096)); }
-    auto add_ln = [&](size_t w_off, size_t b_off, bool last) {
-        KernelTimer kt(c, PCE_K_LAYERNORM);
+    const bool flat = c->gemm_flat && d % F_T == 0 && M >= 2048 && gemm_flat_offsets_fit(M, 4 * d, 4 * d, 4 * d, 0, 0) &&
+                      gemm_flat_offsets_fit(M, d, d, 0, W_CTX, AT_SP);
+    if (flat) {
+        PCE_HIP(c, w->delta.reserve(sizeof(bf16) * (size_t)M * d)); PCE_HIP(c, w->delta2.reserve(sizeof(bf16) * (size_t)M * d));
+        PCE_HIP(c, w->d_enc_bf16.reserve(sizeof(bf16) * (size_t)M * d + 4096));
+    }
+    // mid = the pass after the attention projection (x = resid + delta feeds ln2, the stream is not written), else the pass at the end of
+    // the layer (x = (resid + delta) + delta2 is written back and feeds the next layer's ln1, or ln_post -> the fp32 encoder output)
+    auto add_ln = [&](size_t w_off, size_t b_off, bool mid, bool last) {
+        KernelTimer kt(c, PCE_K_ADD_LAYERNORM);
+        const bf16 *d2 = mid ? nullptr : w->delta2.as<bf16>();
         if (last)
-            hipLaunchKernelGGL((k_add_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(),
+            hipLaunchKernelGGL((k_add_layernorm<float>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(), d2, 1,
                                Wf + w_off, Wf + b_off, M, d, w->final_out.as<float>(), 1e-5f, w->d_enc_bf16.as<bf16>());   // + the bf16 copy the decoder's cross K / V projections read
         else
-            hipLaunchKernelGGL((k_add_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(),
-                               Wf + w_off, Wf + b_off, M, d, w->ln_out.as<bf16>(), 1e-5f);
+            hipLaunchKernelGGL((k_add_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), w->delta.as<bf16>(), d2,
+                               mid ? 0 : 1, Wf + w_off, Wf + b_off, M, d, w->ln_out.as<bf16>(), 1e-5f);
     };
     for (int l = 0; l < L; l++) {
         const WhisperState::Layer &ly = w->layers[(size_t)l];
@@ -1839,13 +1875,11 @@ int pce_whisper_encode_run(pce_ctx *c)
             hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(M, 4)), dim3(256), 0, c->stream, w->resid.as<float>(), Wf + ly.ln1_w,
                                Wf + ly.ln1_b, M, d, w->ln_out.as<bf16>());
         }
-        // Q | K go to the row-major [M][2d] buffer, V is written transposed per head
-        bool done = flat && launch_gemm_flat<FEPI_BF16>(c, w->ln_out.as<bf16>(), Wb + ly.qkv_w, Wf + ly.qkv_b, w->qkv.as<bf16>(), (int)M, 2 * d, d, 2 * d);
-        if (done) {
-            if (!launch_gemm_flat<FEPI_VT>(c, w->ln_out.as<bf16>(), Wb + ly.qkv_w + (size_t)2 * d * d, Wf + ly.qkv_b + 2 * d, w->vt.as<bf16>(), (int)M, d, d, 0,
-                                           W_CTX, AT_SP))
-                return pce_fail(c, PCE_E_LIMIT, "transposed-V projection does not fit the 256 x 256 kernel");
-        } else
+        // Q | K go to the row-major [M][2d] buffer, V is written transposed per head: one launch sweeps the LayerNorm output once
+        const bool done = flat && launch_gemm_flat<FEPI_SPLIT>(c, w->ln_out.as<bf16>(), Wb + ly.qkv_w, Wf + ly.qkv_b, w->qkv.as<bf16>(), (int)M, 3 * d, d, 2 * d,
+                                                                W_CTX, AT_SP, PCE_K_GEMM_FLAT_QKV, w->vt.as<bf16>(), 2 * d);
+        if (flat && !done) return pce_fail(c, PCE_E_LIMIT, "Q | K | V projection does not fit the 256 x 256 kernel");
+        if (!done)
             launch_gemm<EPI_QKV>(c, w->ln_out.as<bf16>(), d, 0, Wb + ly.qkv_w, (int)M, 3 * d, d, Wf + ly.qkv_b, w->qkv.as<bf16>(), 2 * d, 0, 1,
                                  reinterpret_cast<const float *>(w->vt.as<bf16>()), W_CTX, 2 * d, AT_SP);
         {
@@ -1854,18 +1888,17 @@ int pce_whisper_encode_run(pce_ctx *c)
             a.vt = w->vt.as<bf16>(); a.vt_clip = (int64_t)d * AT_SP; a.vt_sp = AT_SP;
             a.q_row0 = a.k_row0 = w->enc_tab.as<int>(); a.q_len = a.k_len = w->enc_tab.as<int>() + n;
             a.out = w->attn.as<bf16>(); a.out_ld = d; a.causal = 0;
-            KernelTimer kt(c, PCE_K_ATTENTION, nullptr, 4.0 * W_CTX * (double)W_CTX * d * n);
-            launch_attention(c, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), a);
+            launch_attention(c, dim3((unsigned)div_up(W_CTX, AT_QB), (unsigned)H, (unsigned)n), a, 4.0 * W_CTX * (double)W_CTX * d * n);
         }
         if (flat) {
-            if (!launch_gemm_flat<FEPI_BF16>(c, w->attn.as<bf16>(), Wb + ly.out_w, Wf + ly.out_b, w->delta.as<bf16>(), (int)M, d, d, d))
+            if (!launch_gemm_flat<FEPI_BF16>(c, w->attn.as<bf16>(), Wb + ly.out_w, Wf + ly.out_b, w->delta.as<bf16>(), (int)M, d, d, d, 1, 0, PCE_K_GEMM_FLAT_OUT))
                 return pce_fail(c, PCE_E_LIMIT, "attention projection does not fit the 256 x 256 kernel");
-            add_ln(ly.ln2_w, ly.ln2_b, false);
-            if (!launch_gemm_flat<FEPI_GELU>(c, w->ln_out.as<bf16>(), Wb + ly.m1_w, Wf + ly.m1_b, w->hidden.as<bf16>(), (int)M, 4 * d, d, 4 * d) ||
-                !launch_gemm_flat<FEPI_BF16>(c, w->hidden.as<bf16>(), Wb + ly.m2_w, Wf + ly.m2_b, w->delta.as<bf16>(), (int)M, d, 4 * d, d))
+            add_ln(ly.ln2_w, ly.ln2_b, true, false);
+            if (!launch_gemm_flat<FEPI_GELU>(c, w->ln_out.as<bf16>(), Wb + ly.m1_w, Wf + ly.m1_b, w->hidden.as<bf16>(), (int)M, 4 * d, d, 4 * d, 1, 0, PCE_K_GEMM_FLAT_FC1) ||
+                !launch_gemm_flat<FEPI_BF16>(c, w->hidden.as<bf16>(), Wb + ly.m2_w, Wf + ly.m2_b, w->delta2.as<bf16>(), (int)M, d, 4 * d, d, 1, 0, PCE_K_GEMM_FLAT_FC2))
                 return pce_fail(c, PCE_E_LIMIT, "MLP does not fit the 256 x 256 kernel");
-            if (l + 1 < L) add_ln(w->layers[(size_t)l + 1].ln1_w, w->layers[(size_t)l + 1].ln1_b, false);
-            else add_ln(w->lnp_w, w->lnp_b, true);
+            if (l + 1 < L) add_ln(w->layers[(size_t)l + 1].ln1_w, w->layers[(size_t)l + 1].ln1_b, false, false);
+            else add_ln(w->lnp_w, w->lnp_b, false, true);
             continue;
         }
         launch_gemm<EPI_RESID_F32>(c, w->attn.as<bf16>(), d, 0, Wb + ly.out_w, (int)M, d, d, Wf + ly.out_b, w->resid.as<float>(), d, 0, 1);
@@ -1891,9 +1924,8 @@ int pce_whisper_encode_run(pce_ctx *c)
 // encoded audio: W = [K weights | V weights] (2d rows of d).  On the persistent 256 x 256 kernel when the shape fits.
 static void project_cross_kv(pce_ctx *c, const bf16 *enc, int Ma, int d, const bf16 *W, const float *bias, bf16 *xk, bf16 *xvt)
 {
-    if (launch_gemm_flat<FEPI_BF16>(c, enc, W, bias, xk, Ma, d, d, d)) {
-        if (launch_gemm_flat<FEPI_VT>(c, enc, W + (size_t)d * d, bias + d, xvt, Ma, d, d, 0, W_CTX, AT_SP)) return;
-    }
+    // one launch: K columns leave row-major, V columns as the transposed image (the 590 MB of encoded audio are swept once)
+    if (launch_gemm_flat<FEPI_SPLIT>(c, enc, W, bias, xk, Ma, 2 * d, d, d, W_CTX, AT_SP, PCE_K_GEMM_FLAT_XKV, xvt, d)) return;
     launch_gemm<EPI_QKV>(c, enc, d, 0, W, Ma, 2 * d, d, bias, xk, d, 0, 1, reinterpret_cast<const float *>(xvt), W_CTX, d, AT_SP);
 }
 
@@ -1950,7 +1982,8 @@ int pce_selftest_gemm(pce_ctx *c, const uint16_t *A, const uint16_t *B, const fl
 {
     if (!c || !A || !B || !out || M <= 0 || N <= 0 || K <= 0) return PCE_E_INVALID;
     PCE_HIP(c, hipSetDevice(c->device));
-    const size_t n_out = epilogue == 2 ? (size_t)(M / rows_per_clip) * N * vt_sp : (size_t)M * N;
+    const size_t n_out = epilogue == 2 ? (size_t)(M / rows_per_clip) * N * vt_sp
+                         : epilogue >= 256 ? (size_t)M * epilogue + (size_t)(M / rows_per_clip) * (N - epilogue) * vt_sp : (size_t)M * N;
     DevBuf dA, dB, dC, dbias;
     PCE_HIP(c, dA.reserve((size_t)M * K * 2)); PCE_HIP(c, dB.reserve((size_t)N * K * 2)); PCE_HIP(c, dC.reserve(n_out * 2)); PCE_HIP(c, dbias.reserve((size_t)N * 4));
     PCE_HIP(c, hipMemcpyAsync(dA.p, A, (size_t)M * K * 2, hipMemcpyHostToDevice, c->stream));
@@ -1962,6 +1995,9 @@ int pce_selftest_gemm(pce_ctx *c, const uint16_t *A, const uint16_t *B, const fl
     if (epilogue == 0) ok = launch_gemm_flat<FEPI_BF16>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, N);
     else if (epilogue == 1) ok = launch_gemm_flat<FEPI_GELU>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, N);
     else if (epilogue == 2) ok = launch_gemm_flat<FEPI_VT>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, 0, rows_per_clip, vt_sp);
+    else if (epilogue >= 256 && epilogue % 256 == 0 && epilogue < N)      // split launch: columns [0, epilogue) row-major [M][epilogue], then the V^T image of the rest
+        ok = launch_gemm_flat<FEPI_SPLIT>(c, dA.as<bf16>(), dB.as<bf16>(), bp, dC.as<bf16>(), M, N, K, epilogue, rows_per_clip, vt_sp, PCE_K_GEMM_FLAT,
+                                          dC.as<bf16>() + (size_t)M * epilogue, epilogue);
     int rc = PCE_OK;
     if (!ok) rc = pce_fail(c, PCE_E_LIMIT, "shape not handled by the 256 x 256 kernel (N %% 256, K %% 64, M >= 2048)");
     else {

@@ -95,8 +95,11 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(PitchSummary)
 SLICE_OK, SLICE_TOO_SHORT, SLICE_EMPTY = 0, 1, 2
 
 KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs_gate",
-              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
-              "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat"]
+              "k_pitch_refine", "k_pitch_frames", "k_pitch_path", "k_pitch_median", "k_pitch_delta", "k_stft_max", "k_stft_db", "k_logmel_frames", "whisper_encoder", "k_resample", "k_dtw", "whisper_align", "k_nw", "k_stft_norm", "k_frame_energy", "bert_forward", "k_pyin_frames", "k_pyin_viterbi", "whisper_decode_step",
+              "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat",
+              "k_add_layernorm", "k_stft_raw", "k_logmel_norm", "k_attention_lean",
+              "k_gemm_flat:qkv", "k_gemm_flat:out", "k_gemm_flat:fc1", "k_gemm_flat:fc2", "k_gemm_flat:xkv",
+              "whisper_decode_loop", "k_cross_attn1"]     # = pce_kernel_name(id) for every id (tests/test_abi_and_shard.py)
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -410,18 +413,22 @@ class ProsodyEngine:
 
     def selftest_gemm(self, A, B, bias=None, epilogue: int = 0, rows_per_clip: int = 1, vt_sp: int = 0):
         """C = epilogue(A B^T + bias) on the persistent 256 x 256 GEMM kernel; A [M][K], B [N][K] float arrays (rounded to bf16 here) ->
-        float32 result decoded from bf16 ([M][N], or [clips][N][vt_sp] for the transposed epilogue 2)."""
+        float32 result decoded from bf16 ([M][N], or [clips][N][vt_sp] for the transposed epilogue 2).  ``epilogue`` >= 256 (a multiple of 256, < N)
+        is the split launch: returns (row-major [M][epilogue], transposed image [clips][N - epilogue][vt_sp])."""
         import torch
         a = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float32)).to(torch.bfloat16).contiguous()
         b = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float32)).to(torch.bfloat16).contiguous()
         M, K = a.shape; N = b.shape[0]
-        n_out = (M // rows_per_clip) * N * vt_sp if epilogue == 2 else M * N
+        split = epilogue if epilogue >= 256 else 0
+        n_out = (M // rows_per_clip) * N * vt_sp if epilogue == 2 else M * split + (M // rows_per_clip) * (N - split) * vt_sp if split else M * N
         out = torch.zeros(n_out, dtype=torch.bfloat16)
         bv = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
         self._check(self._lib.pce_selftest_gemm(self._ctx, a.view(torch.int16).numpy().ctypes.data, b.view(torch.int16).numpy().ctypes.data,
                                                 bv.ctypes.data if bv is not None else None, M, N, K, int(epilogue), int(rows_per_clip), int(vt_sp),
                                                 out.view(torch.int16).numpy().ctypes.data))
         res = out.float().numpy()
+        if split:
+            return res[:M * split].reshape(M, split), res[M * split:].reshape(M // rows_per_clip, N - split, vt_sp)
         return res.reshape(M // rows_per_clip, N, vt_sp) if epilogue == 2 else res.reshape(M, N)
 
     def selftest_attention(self, q, k, v, causal: bool = False, mode: int = 0):

@@ -408,6 +408,32 @@ def test_persistent_256_gemm_against_torch(engine, shape):
     assert (err <= np.abs(want) * 2.0 ** -7 + 1e-2).all(), np.argwhere(err > np.abs(want) * 2.0 ** -7 + 1e-2)[:8]
 
 
+@pytest.mark.parametrize("shape", [(3000, 2304, 768, 1536), (4500, 1536, 768, 768), (6000, 512, 128, 256)])
+def test_persistent_256_gemm_split_launch(engine, shape):
+    """Round 3: ONE launch for Q | K | V (N = 3 d, the last d columns as the transposed image) and for the cross-attention K | V
+    (N = 2 d): the row-major part and the V^T image both equal what the two separate launches (epilogues 0 and 2) write, BIT FOR BIT
+    (same fragments, same summation order: the transposed tiles are computed as the transposed problem), and match torch fp32 on the
+    bf16-rounded operands.  M = 4 500 / 6 000: tiles that straddle a clip boundary (1 500 rows per clip), also in the middle of a
+    lane's eight key positions."""
+    import torch
+    M, N, K, split = shape
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32); B = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    S = 1500
+    rm, vt = engine.selftest_gemm(A, B, bias, split, S, 1536)
+    assert rm.shape == (M, split) and vt.shape == (M // S, N - split, 1536)
+    assert np.array_equal(rm, engine.selftest_gemm(A, B[:split], bias[:split], 0))
+    assert np.array_equal(vt, engine.selftest_gemm(A, B[split:], bias[split:], 2, S, 1536))
+    assert not vt[:, :, S:].any()
+    a = torch.from_numpy(A).to(torch.bfloat16).float(); b = torch.from_numpy(B).to(torch.bfloat16).float()
+    want = (a @ b.T + torch.from_numpy(bias)).numpy()
+    got = np.concatenate([rm, np.concatenate([vt[c, :, :S].T for c in range(M // S)])], axis=1)
+    err = np.abs(got - want)
+    assert np.linalg.norm(err) / np.linalg.norm(want) <= 4e-3
+    assert (err <= np.abs(want) * 2.0 ** -7 + 1e-2).all()
+
+
 def test_persistent_256_gemm_is_deterministic_and_row_count_independent(engine):
     """Each output element is one lane's fixed-order sum: a row block gives the same BITS whether 6 000 or 96 000 rows are in
     the product (other tile order, other workgroup, other ring phase), run after run.  (Two scheduling bugs showed up as
