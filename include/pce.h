@@ -306,6 +306,19 @@ int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_
                                int32_t *next_tokens /* [clips] */, float *next_logprobs /* [clips] or NULL */,
                                float *probe_prob /* [clips] or NULL */);
 
+/* The whole free-running loop on the device (round 3): what whisper.decoding.DecodingTask._main_loop does for a batch
+ * (Code/Aligners/use_whisper_timestamped.py:150-163 -> whisper_timestamped.transcribe -> whisper.decode).  The prompts are uploaded
+ * once; every later step takes the token it embeds, its position and the "ended" flags from device memory written by the previous
+ * step; the host synchronises every `check_every` steps (<= 0: 4) to read ONE counter and once at the end for the results.
+ * A sequence that has produced end-of-text keeps receiving it (log-probability 0), as GreedyDecoder.update pads finished
+ * sequences; the loop stops when every sequence has ended or after max_new steps.  out_tokens / out_logprobs: [clips][max_new]
+ * (entries of steps that did not run: eot / 0); *out_steps = steps run.  opts / probe_prob as pce_whisper_decode_step_ex (the probe
+ * belongs to step 0).  Token for token the sequence of pce_whisper_decode_step_ex calls it replaces. */
+int pce_whisper_decode_loop(pce_ctx *ctx, const int32_t *tokens, const int32_t *token_offsets /* [clips + 1] */,
+                            const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts,
+                            int32_t max_new, int32_t check_every, int32_t *out_tokens, float *out_logprobs /* or NULL */,
+                            int32_t *out_steps, float *probe_prob /* [clips] or NULL */);
+
 /* ---- R8: dynamic time warping (alignment indices) ------------------------
  * The DTW of openai-whisper's timing.py (dtw_cpu) that whisper_timestamped's word alignment rests on
  * (Code/Aligners/use_whisper_timestamped.py:163): x is `batch` row-major [n_rows][n_cols] fp64 cost matrices

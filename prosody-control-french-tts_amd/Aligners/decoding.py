@@ -47,11 +47,13 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
 
 
 def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, sample_len: int, temperature: float = 0.0, seed: int = 0,
-                 active=None, no_cache: bool = False):
+                 active=None, no_cache: bool = False, device_loop: bool = True):
     """``greedy_decode`` with one prompt per clip (``condition_on_previous_text`` gives every recording its own) and an
     optional temperature (GreedyDecoder at temperature t: one sample per step from softmax(filtered logits / t)).
     ``active[i]`` False: the clip is left alone (it reads as ended from the first step on).
-    -> (sampled tokens per clip, end-of-text cut off; their log-probabilities per clip; sum_logprobs [clips])."""
+    -> (sampled tokens per clip, end-of-text cut off; their log-probabilities per clip; sum_logprobs [clips]).
+    ``device_loop`` (default): the step loop runs inside the engine (``pce_whisper_decode_loop``: prompts up once, results down
+    once); False: one ``whisper_decode_step_ex`` round trip per step -- the form the device loop is checked against."""
     n = engine.whisper_num_encoded()
     eot = rules["eot"]
     active = [True] * n if active is None else list(active)
@@ -59,6 +61,16 @@ def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, samp
     begins = np.asarray([b if a else b for b, a in zip(sample_begins, active)], dtype=np.int32)
     mask = vocab_mask(n_vocab, rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
     lps = [[] for _ in range(n)]
+    if device_loop and not no_cache and sample_len >= 1:            # (no_cache asks for the prefix re-run every step: only the host-driven form has it)
+        toks, lp, _ = engine.whisper_decode_loop(seqs, begins, eot, rules["timestamp_begin"], mask, int(sample_len), rules.get("max_initial_timestamp_index"),
+                                                 temperature=temperature, seed=seed, no_cache=no_cache)
+        for step in range(toks.shape[1]):
+            for i in range(n):
+                ended = seqs[i][-1] == eot and len(seqs[i]) > begins[i]
+                seqs[i].append(int(toks[i, step]))
+                if not ended:
+                    lps[i].append(float(lp[i, step]))
+        sample_len = 0                                              # (the loop below has nothing left to do)
     for _ in range(sample_len):
         nxt, lp, _ = engine.whisper_decode_step_ex(seqs, begins, eot, rules["timestamp_begin"], mask, rules.get("max_initial_timestamp_index"),
                                                    temperature=temperature, seed=seed, no_cache=no_cache)

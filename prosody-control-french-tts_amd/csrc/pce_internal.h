@@ -53,6 +53,7 @@ struct pce_ctx {
     bool generic_median = false;         // PCE_ALIGN_GENERIC_MEDIAN at pce_create: the insertion-sort median filter for every width
     // debugging / tuning knobs, read once at pce_create (never in a launch path)
     bool dbg_pitch_lds_fft = false; int dbg_pitch_tabs = -1, dbg_pitch = 0, refine_blocks_per_cu = 24;
+    bool attn1 = true;                   // PCE_ATTN1=0 at pce_create: incremental decoding steps keep the MFMA attention kernel (one live query per tile) instead of k_cross_attn1
     int attn_mode = 1;                   // PCE_ATTN at pce_create: 1 = k_attention_lean (default), 2 = its exact path only, 0 = k_attention (round 1)
     int gemm_sm = 0, gemm_sn = 0, gemm_wide = -1; bool gemm_trace = false;   // PCE_GEMM_SM / _SN / _WIDE / _TRACE: rasterisation and tile-shape overrides, phase stamps (tiled kernels)
     bool gemm_flat_attr[4] = {false, false, false, false};   // k_gemm_flat<EPI>: dynamic-LDS opt-in done on this context's device

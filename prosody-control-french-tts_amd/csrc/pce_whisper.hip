@@ -1088,6 +1088,131 @@ __global__ void k_embed_one(const int *__restrict__ tok, const float *__restrict
     out[i] = tok_emb[(int64_t)tok[clip] * d + col] + pos_emb[(int64_t)pos_of[clip] * d + col];
 }
 
+// ---- device-resident decoding loop (round 3) -----------------------------------------------------------------------------------
+// After the logit filters have chosen `next` for every sequence, k_step_advance appends it to the device-resident token table,
+// refreshes the per-sequence tables the NEXT step's kernels read (new token, position, self-attention key count, "ended" flag),
+// records the step's outputs and counts the sequences whose last token is end-of-text.  Nothing of a step passes through the host.
+// tables ct[8 n]: new token | q_row0 | q_len | k_row0 | k_len | a_row0 | a_len | position   (the layout pce_whisper_decode_step_ex uploads)
+__global__ __launch_bounds__(256) void k_step_advance(int n, int T_cap, int eot, int max_new, int *__restrict__ tok_table, int *__restrict__ len,
+                                                     const int *__restrict__ next, const float *__restrict__ next_lp, int *__restrict__ ct,
+                                                     int *__restrict__ ended, int *__restrict__ out_tok, float *__restrict__ out_lp,
+                                                     int *__restrict__ step_ctr, int *__restrict__ n_ended)
+{   // ONE workgroup (a few hundred sequences)
+    const int step = *step_ctr;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int L = len[i], t = next[i];
+        if (step < max_new) { out_tok[(size_t)i * max_new + step] = t; out_lp[(size_t)i * max_new + step] = next_lp[i]; }
+        if (L < T_cap) { tok_table[(size_t)i * T_cap + L] = t; len[i] = L + 1; }
+        ct[i] = t; ct[4 * n + i] = (L < T_cap ? L : T_cap - 1) + 1; ct[7 * n + i] = L < T_cap ? L : T_cap - 1;
+        const int e = t == eot;
+        ended[i] = e; cnt += e;
+    }
+    if (cnt) atomicAdd(n_ended + (step < max_new ? step : max_new - 1), cnt);
+    if (threadIdx.x == 0) *step_ctr = step + 1;
+}
+
+// Attention of ONE query per (clip, head) over a long key axis: the cross-attention (1 500 audio positions) and the cached
+// self-attention of an incremental decoding step.  The MFMA attention kernels spend a 32-query tile on it and walk the keys as 24
+// dependent LDS-DMA tiles per workgroup; this is a streaming kernel: HBM-bound by construction (one pass over K, one over V^T:
+// 14 GB per step for 256 clips at Whisper-small size, the roofline of free-running decoding).
+//   phase 1: scores.  8 lanes per key row (16 B = 8 dims each: a wave-instruction covers eight whole 128-byte lines), eight rows per lane
+//            in flight, 8-lane sums by DPP -> fp32 scores in LDS
+//   phase 2: softmax (fp32, max-subtracted) in LDS
+//   phase 3: O[d] = sum_t p[t] V^T[d][t]: a wave streams one V^T row as 1 KB pieces (lane = 8 consecutive keys, p in registers), 16 rows per wave
+// `skip[clip]` != 0: the sequence has ended, its output is never used (the filters return end-of-text for it): no bytes are read.
+struct Attn1Args {
+    const bf16 *q; int64_t q_ld;              // query of clip c: q + c * q_ld + head * 64
+    const bf16 *k; int64_t k_ld;              // key row j:       k + (k_row0[c] + j) * k_ld + head * 64
+    const bf16 *vt; int64_t vt_clip; int vt_sp;   // V^T:        vt + c * vt_clip + (head * 64 + d) * vt_sp + j   (columns >= k_len hold finite values)
+    const int *k_row0, *k_len;                // per clip; k_len <= 1536
+    const int *skip;                          // per clip or null
+    bf16 *out; int64_t out_ld;                // out + c * out_ld + head * 64
+};
+__global__ __launch_bounds__(256) void k_cross_attn1(Attn1Args A)
+{
+    __shared__ float sp[1536];
+    __shared__ float red[8];
+    __shared__ float so[64];
+    const int head = blockIdx.x, clip = blockIdx.y;
+    if (A.skip && A.skip[clip]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int Sk = A.k_len[clip];
+    const int g = lane >> 3, ch = lane & 7;
+    float qf[8];
+    {
+        const bf16x8 qv = *reinterpret_cast<const bf16x8 *>(A.q + (int64_t)clip * A.q_ld + head * 64 + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qf[e] = (float)qv[e] * 0.125f;
+    }
+    const bf16 *kb = A.k + (int64_t)A.k_row0[clip] * A.k_ld + head * 64 + ch * 8;
+    constexpr int U = 8;
+    for (int base = wv * 8; base < Sk; base += 32 * U) {
+        bf16x8 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = base + u * 32 + g;
+            kv[u] = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)(r < Sk ? r : Sk - 1) * A.k_ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) d = fmaf((float)kv[u][e], qf[e], d);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            const int r = base + u * 32 + g;
+            if (ch == 0 && r < Sk) sp[r] = d;
+        }
+    }
+    __syncthreads();
+    float m = -3.0e38f;
+    for (int t = tid; t < Sk; t += 256) m = fmaxf(m, sp[t]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    const int Sp = (Sk + 511) & ~511;                            // p is read in 512-key pieces: zero beyond the last key
+    for (int t = tid; t < Sp; t += 256) {
+        const float pv = t < Sk ? __expf(sp[t] - m) : 0.f;
+        sp[t] = pv; sum += pv;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    const int np = Sp >> 9;                                      // 1..3 pieces
+    float pr[3][8];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) pr[j][e] = j < np ? sp[j * 512 + lane * 8 + e] : 0.f;
+    const bf16 *vb = A.vt + (int64_t)clip * A.vt_clip + (int64_t)(head * 64 + wv * 16) * A.vt_sp + lane * 8;
+#pragma unroll
+    for (int r4 = 0; r4 < 16; r4 += 4) {
+        bf16x8 vv[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (j < np) vv[r][j] = *reinterpret_cast<const bf16x8 *>(vb + (int64_t)(r4 + r) * A.vt_sp + j * 512);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (j < np)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) a = fmaf(pr[j][e], (float)vv[r][j][e], a);
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0) so[wv * 16 + r4 + r] = a * inv;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) A.out[(int64_t)clip * A.out_ld + head * 64 + tid] = (bf16)so[tid];
+}
+
 // openai-whisper decoding.py at temperature 0, one workgroup per sequence: SuppressBlank, SuppressTokens,
 // ApplyTimestampRules on the logits of the last position, then the GreedyDecoder's arg-max (first maximum) and its
 // "once end-of-text, always end-of-text" rule.  vmask: bit 0 = always suppressed (suppress list, no_timestamps),
@@ -1450,7 +1575,7 @@ struct WhisperState {
     DevBuf g_emb_bf16, g_xk, g_xvt, g_last, g_lastln, g_logits, g_mask, g_next;
     int g_xkv_clips = -1;            // clips the cross K / V cache was computed for (-1: stale)
     // self-attention K / V of the sequences decoded so far: K rows [layer][clip][T_cap][d], V^T [layer][clip][d][512]
-    DevBuf g_sk, g_svt, g_c_resid, g_c_ln, g_c_qkv, g_c_attn, g_c_q, g_c_hidden, g_c_tab;
+    DevBuf g_sk, g_svt, g_c_resid, g_c_ln, g_c_qkv, g_c_attn, g_c_q, g_c_hidden, g_c_tab, g_loop;
     std::vector<int> g_cache_tok;     // host copy of the cached prefixes [clip][T_cap]
     int g_cache_len = -1, g_cache_n = -1;   // g_cache_len: < 0 = nothing cached (new encoded batch); per-sequence lengths in g_cache_lens
     std::vector<int> g_cache_lens;
@@ -1635,7 +1760,7 @@ void pce_whisper_free(pce_ctx *c)
                       &w->ln_out, &w->qkv, &w->vt, &w->attn, &w->enc_tab, &w->delta, &w->delta2, &w->dw_bf16, &w->dw_f32, &w->d_tok_emb, &w->d_pos_emb, &w->d_tab,
                       &w->d_tokens, &w->d_resid, &w->d_ln, &w->d_qk, &w->d_vt, &w->d_attn, &w->d_q, &w->d_hidden, &w->d_enc_bf16, &w->d_aw,
                       &w->d_cost, &w->d_trace, &w->d_pi, &w->d_pj, &w->d_pl, &w->d_heads, &w->hidden, &w->final_out,
-                      &w->g_sk, &w->g_svt, &w->g_c_resid, &w->g_c_ln, &w->g_c_qkv, &w->g_c_attn, &w->g_c_q, &w->g_c_hidden, &w->g_c_tab,
+                      &w->g_sk, &w->g_svt, &w->g_c_resid, &w->g_c_ln, &w->g_c_qkv, &w->g_c_attn, &w->g_c_q, &w->g_c_hidden, &w->g_c_tab, &w->g_loop,
                       &w->g_emb_bf16, &w->g_xk, &w->g_xvt, &w->g_last, &w->g_lastln, &w->g_logits, &w->g_mask, &w->g_next,
                       &w->bert.w_bf16, &w->bert.w_f32, &w->bert.word, &w->bert.pos, &w->bert.type0, &w->bert.tab, &w->bert.tokens, &w->bert.resid,
                       &w->bert.ln, &w->bert.qk, &w->bert.vt, &w->bert.attn, &w->bert.hidden, &w->bert.logits};
@@ -2298,11 +2423,100 @@ extern "C" int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const 
     return pce_whisper_decode_step_ex(c, tokens, token_offsets, rules, vocab_mask, &o, next_tokens, next_logprobs, nullptr);
 }
 
+// launches of ONE incremental step (one new position per sequence) from the tables ct[8 n] (see k_step_advance) -- host-uploaded by
+// pce_whisper_decode_step_ex, device-maintained inside pce_whisper_decode_loop -- down to the final LayerNorm of the new position
+static void decode_incremental_launches(pce_ctx *c, WhisperState *w, int n, const int *CT, const int *ended)
+{
+    const int d = w->tdims.n_state, H = w->tdims.n_head, L = w->tdims.n_layer, SPD = 512, T_cap = w->tdims.n_text_ctx;
+    const int64_t Ma = (int64_t)n * W_CTX;
+    const size_t xk_l = (size_t)Ma * d, xvt_l = (size_t)n * (size_t)d * AT_SP, sk_l = (size_t)n * T_cap * d, svt_l = (size_t)n * (size_t)d * SPD;
+    const bf16 *Wb = w->dw_bf16.as<bf16>();
+    const float *Wf = w->dw_f32.as<float>();
+    const int *Q0 = CT + n, *QL = CT + 2 * n, *K0 = CT + 3 * n, *KL = CT + 4 * n, *X0 = CT + 5 * n, *XL = CT + 6 * n, *POS = CT + 7 * n;
+    hipLaunchKernelGGL(k_embed_one, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, CT, w->d_tok_emb.as<float>(),
+                       w->d_pos_emb.as<float>(), POS, d, n, w->g_c_resid.as<float>());
+    auto cattn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp, const int *k0, const int *kl) {
+        if (c->attn1) {                                           // streaming single-query kernel (PCE_ATTN1=0: the MFMA attention kernel with one live query)
+            Attn1Args a{};
+            a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp; a.k_row0 = k0; a.k_len = kl; a.skip = ended;
+            a.out = w->g_c_attn.as<bf16>(); a.out_ld = d;
+            KernelTimer kt(c, PCE_K_CROSS_ATTN1);
+            hipLaunchKernelGGL(k_cross_attn1, dim3((unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+            return;
+        }
+        AttnArgs a{};
+        a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
+        a.q_row0 = Q0; a.q_len = QL; a.k_row0 = k0; a.k_len = kl; a.out = w->g_c_attn.as<bf16>(); a.out_ld = d; a.causal = 0;
+        launch_attention(c, dim3(1u, (unsigned)H, (unsigned)n), a);
+    };
+    auto cln = [&](size_t w_off, size_t b_off) {
+        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w_off, Wf + b_off,
+                           (int64_t)n, d, w->g_c_ln.as<bf16>());
+    };
+    for (int l = 0; l < L; l++) {
+        const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
+        cln(ly.ln1_w, ly.ln1_b);
+        launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, n, 3 * d, d, Wf + ly.qkv_b, w->g_c_qkv.as<bf16>(), 3 * d, 0, 1);
+        hipLaunchKernelGGL(k_append_kv, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, w->g_c_qkv.as<bf16>(), POS, d, T_cap, SPD, n,
+                           w->g_sk.as<bf16>() + sk_l * (size_t)l, w->g_svt.as<bf16>() + svt_l * (size_t)l);
+        cattn(w->g_c_qkv.as<bf16>(), 3 * d, w->g_sk.as<bf16>() + sk_l * (size_t)l, d, w->g_svt.as<bf16>() + svt_l * (size_t)l, (int64_t)d * SPD, SPD, K0, KL);
+        launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.out_w, n, d, d, Wf + ly.out_b, w->g_c_resid.as<float>(), d, 0, 1);
+        cln(ly.lnx_w, ly.lnx_b);
+        launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.xq_w, n, d, d, Wf + ly.xq_b, w->g_c_q.as<bf16>(), d, 0, 1);
+        cattn(w->g_c_q.as<bf16>(), d, w->g_xk.as<bf16>() + xk_l * (size_t)l, d, w->g_xvt.as<bf16>() + xvt_l * (size_t)l, (int64_t)d * AT_SP, AT_SP, X0, XL);
+        launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.xout_w, n, d, d, Wf + ly.xout_b, w->g_c_resid.as<float>(), d, 0, 1);
+        cln(ly.ln2_w, ly.ln2_b);
+        launch_gemm<EPI_GELU_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.m1_w, n, 4 * d, d, Wf + ly.m1_b, w->g_c_hidden.as<bf16>(), 4 * d, 0, 1);
+        launch_gemm<EPI_RESID_F32>(c, w->g_c_hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, n, d, 4 * d, Wf + ly.m2_b, w->g_c_resid.as<float>(), d, 0, 1);
+    }
+    hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w->dln_w, Wf + w->dln_b,
+                       (int64_t)n, d, w->g_lastln.as<bf16>());
+}
+static int decode_incremental_reserve(pce_ctx *c, WhisperState *w, int n)
+{
+    const int d = w->tdims.n_state;
+    PCE_HIP(c, w->g_c_tab.reserve(sizeof(int) * 8 * (size_t)n));
+    PCE_HIP(c, w->g_c_resid.reserve(sizeof(float) * (size_t)n * d));
+    PCE_HIP(c, w->g_c_ln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+    PCE_HIP(c, w->g_c_qkv.reserve(sizeof(bf16) * (size_t)(n + 128) * 3 * d + 4096));
+    {
+        const size_t before = w->g_c_attn.cap;
+        PCE_HIP(c, w->g_c_attn.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+        if (w->g_c_attn.cap != before) PCE_HIP(c, hipMemsetAsync(w->g_c_attn.p, 0, w->g_c_attn.cap, c->stream));   // rows of ended sequences are skipped: never uninitialised bits
+    }
+    PCE_HIP(c, w->g_c_q.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
+    PCE_HIP(c, w->g_c_hidden.reserve(sizeof(bf16) * (size_t)(n + 128) * 4 * d + 4096));
+    return PCE_OK;
+}
+
+// one decoding step; results stay on the device in g_next (next token | log-probability | probe probability, n each).  `resident`: the
+// caller (pce_whisper_decode_loop) keeps the tables of an incremental step on the device: `tokens` is then only consulted for step 0.
+static int decode_step_device(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, const pce_whisper_decode_rules *rules,
+                              const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts, bool want_probe);
+
 extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, const pce_whisper_decode_rules *rules,
                                           const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts, int32_t *next_tokens,
                                           float *next_logprobs, float *probe_prob)
 {
     if (!c || !tokens || !token_offsets || !rules || !vocab_mask || !next_tokens || !opts) return PCE_E_INVALID;
+    const int rc = decode_step_device(c, tokens, token_offsets, rules, vocab_mask, opts, probe_prob != nullptr);
+    if (rc) return rc;
+    WhisperState *w = ws_of(c);
+    const int n = w->n_clips_enc;
+    if (n == 0) return PCE_OK;
+    PCE_HIP(c, hipMemcpyAsync(next_tokens, w->g_next.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (next_logprobs) PCE_HIP(c, hipMemcpyAsync(next_logprobs, w->g_next.as<int>() + n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (probe_prob && opts->probe_token >= 0)
+        PCE_HIP(c, hipMemcpyAsync(probe_prob, w->g_next.as<int>() + 2 * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    return PCE_OK;
+}
+
+static int decode_step_device(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, const pce_whisper_decode_rules *rules,
+                              const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts, bool want_probe)
+{
+    float probe_dummy = 0.f;
+    float *probe_prob = want_probe ? &probe_dummy : nullptr;      // (only its non-nullness is consulted below)
     const int32_t sample_begin = opts->sample_begin_all;
     WhisperState *w = ws_of(c);
     if (!w->dec_loaded) return pce_fail(c, PCE_E_STATE, "pce_whisper_decode_step before pce_whisper_decoder_load");
@@ -2399,47 +2613,10 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
             ct[(size_t)i] = tokens[token_offsets[i] + pos_i]; ct[(size_t)n + i] = i; ct[(size_t)2 * n + i] = 1; ct[(size_t)3 * n + i] = i * T_cap;
             ct[(size_t)4 * n + i] = pos_i + 1; ct[(size_t)5 * n + i] = i * W_CTX; ct[(size_t)6 * n + i] = W_CTX; ct[(size_t)7 * n + i] = pos_i;
         }
-        PCE_HIP(c, w->g_c_tab.reserve(sizeof(int) * ct.size()));
-        PCE_HIP(c, w->g_c_resid.reserve(sizeof(float) * (size_t)n * d));
-        PCE_HIP(c, w->g_c_ln.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
-        PCE_HIP(c, w->g_c_qkv.reserve(sizeof(bf16) * (size_t)(n + 128) * 3 * d + 4096));
-        PCE_HIP(c, w->g_c_attn.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
-        PCE_HIP(c, w->g_c_q.reserve(sizeof(bf16) * (size_t)(n + 128) * d + 4096));
-        PCE_HIP(c, w->g_c_hidden.reserve(sizeof(bf16) * (size_t)(n + 128) * 4 * d + 4096));
+        { const int rc = decode_incremental_reserve(c, w, n); if (rc) return rc; }
         PCE_HIP(c, hipMemcpyAsync(w->g_c_tab.p, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice, c->stream));
         PCE_HIP(c, hipStreamSynchronize(c->stream));
-        const int *CT = w->g_c_tab.as<int>(), *Q0 = CT + n, *QL = CT + 2 * n, *K0 = CT + 3 * n, *KL = CT + 4 * n, *X0 = CT + 5 * n, *XL = CT + 6 * n,
-                  *POS = CT + 7 * n;
-        hipLaunchKernelGGL(k_embed_one, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, CT, w->d_tok_emb.as<float>(),
-                           w->d_pos_emb.as<float>(), POS, d, n, w->g_c_resid.as<float>());
-        auto cattn = [&](const bf16 *q, int64_t q_ld, const bf16 *k, int64_t k_ld, const bf16 *vt, int64_t vt_clip, int vt_sp, const int *k0, const int *kl) {
-            AttnArgs a{};
-            a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp;
-            a.q_row0 = Q0; a.q_len = QL; a.k_row0 = k0; a.k_len = kl; a.out = w->g_c_attn.as<bf16>(); a.out_ld = d; a.causal = 0;
-            launch_attention(c, dim3(1u, (unsigned)H, (unsigned)n), a);
-        };
-        auto cln = [&](size_t w_off, size_t b_off) {
-            hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w_off, Wf + b_off,
-                               (int64_t)n, d, w->g_c_ln.as<bf16>());
-        };
-        for (int l = 0; l < L; l++) {
-            const WhisperState::DLayer &ly = w->dlayers[(size_t)l];
-            cln(ly.ln1_w, ly.ln1_b);
-            launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.qkv_w, n, 3 * d, d, Wf + ly.qkv_b, w->g_c_qkv.as<bf16>(), 3 * d, 0, 1);
-            hipLaunchKernelGGL(k_append_kv, dim3((unsigned)div_up((int64_t)n * d, 256)), dim3(256), 0, c->stream, w->g_c_qkv.as<bf16>(), POS, d, T_cap, SPD, n,
-                               w->g_sk.as<bf16>() + sk_l * (size_t)l, w->g_svt.as<bf16>() + svt_l * (size_t)l);
-            cattn(w->g_c_qkv.as<bf16>(), 3 * d, w->g_sk.as<bf16>() + sk_l * (size_t)l, d, w->g_svt.as<bf16>() + svt_l * (size_t)l, (int64_t)d * SPD, SPD, K0, KL);
-            launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.out_w, n, d, d, Wf + ly.out_b, w->g_c_resid.as<float>(), d, 0, 1);
-            cln(ly.lnx_w, ly.lnx_b);
-            launch_gemm<EPI_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.xq_w, n, d, d, Wf + ly.xq_b, w->g_c_q.as<bf16>(), d, 0, 1);
-            cattn(w->g_c_q.as<bf16>(), d, w->g_xk.as<bf16>() + xk_l * (size_t)l, d, w->g_xvt.as<bf16>() + xvt_l * (size_t)l, (int64_t)d * AT_SP, AT_SP, X0, XL);
-            launch_gemm<EPI_RESID_F32>(c, w->g_c_attn.as<bf16>(), d, 0, Wb + ly.xout_w, n, d, d, Wf + ly.xout_b, w->g_c_resid.as<float>(), d, 0, 1);
-            cln(ly.ln2_w, ly.ln2_b);
-            launch_gemm<EPI_GELU_BF16>(c, w->g_c_ln.as<bf16>(), d, 0, Wb + ly.m1_w, n, 4 * d, d, Wf + ly.m1_b, w->g_c_hidden.as<bf16>(), 4 * d, 0, 1);
-            launch_gemm<EPI_RESID_F32>(c, w->g_c_hidden.as<bf16>(), 4 * d, 0, Wb + ly.m2_w, n, d, 4 * d, Wf + ly.m2_b, w->g_c_resid.as<float>(), d, 0, 1);
-        }
-        hipLaunchKernelGGL((k_layernorm<bf16>), dim3((unsigned)div_up(n, 4)), dim3(256), 0, c->stream, w->g_c_resid.as<float>(), Wf + w->dln_w, Wf + w->dln_b,
-                           (int64_t)n, d, w->g_lastln.as<bf16>());
+        decode_incremental_launches(c, w, n, w->g_c_tab.as<int>(), nullptr);
         last_ln = w->g_lastln.as<bf16>();
     } else {
     PCE_HIP(c, hipMemsetAsync(w->d_attn.p, 0, sizeof(bf16) * (size_t)Mt * d + 4096, c->stream));      // pad rows: no stale bits (see pce_whisper_align_run)
@@ -2495,11 +2672,110 @@ extern "C" int pce_whisper_decode_step_ex(pce_ctx *c, const int32_t *tokens, con
                        w->g_mask.as<unsigned char>(), R, T0 + 4 * n, w->g_next.as<int>(), reinterpret_cast<float *>(w->g_next.as<int>() + n),
                        reinterpret_cast<float *>(w->g_next.as<int>() + 2 * n));
     PCE_HIP(c, hipGetLastError());
-    PCE_HIP(c, hipMemcpyAsync(next_tokens, w->g_next.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (next_logprobs) PCE_HIP(c, hipMemcpyAsync(next_logprobs, w->g_next.as<int>() + n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    return PCE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Free-running decoding with the loop on the device (round 3).  pce_whisper_decode_step_ex round-trips every step through the
+// host (tokens up, next token down, a synchronisation each way); here the prompts go up once, every later step reads what it
+// needs -- the token it embeds, its position, the self-attention key count, which sequences have ended -- from tables the previous
+// step's k_step_advance left on the device, and the host only looks at an "ended" counter every `check_every` steps.
+// Same kernels, same filters, same counter-based sampling keys (seed, clip, position): token for token what the host-driven loop
+// of Aligners/decoding.py produces (tests/test_gpu_aligner.py).
+// ---------------------------------------------------------------------------
+extern "C" int pce_whisper_decode_loop(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, const pce_whisper_decode_rules *rules,
+                                       const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts, int32_t max_new, int32_t check_every,
+                                       int32_t *out_tokens, float *out_logprobs, int32_t *out_steps, float *probe_prob)
+{
+    if (!c || !tokens || !token_offsets || !rules || !vocab_mask || !opts || !out_tokens || !out_steps) return PCE_E_INVALID;
+    if (max_new < 1) return pce_fail(c, PCE_E_INVALID, "decode loop: max_new must be >= 1");
+    if (check_every < 1) check_every = 4;
+    WhisperState *w = ws_of(c);
+    if (!w->dec_loaded) return pce_fail(c, PCE_E_STATE, "pce_whisper_decode_loop before pce_whisper_decoder_load");
+    if (w->n_clips_enc < 0) return pce_fail(c, PCE_E_STATE, "run pce_whisper_encode_run first");
+    const int n = w->n_clips_enc, d = w->tdims.n_state, V = w->tdims.n_vocab, T_cap = w->tdims.n_text_ctx;
+    *out_steps = 0;
+    if (n == 0) return PCE_OK;
+    for (int i = 0; i < n; i++) {
+        const int T = token_offsets[i + 1] - token_offsets[i];
+        if (T + max_new > T_cap) return pce_fail(c, PCE_E_INVALID, "clip %d: %d prompt tokens + %d new ones exceed the text context (%d)", i, T, max_new, T_cap);
+    }
+    PCE_HIP(c, hipSetDevice(c->device));
+    KernelTimer loop_timer(c, PCE_K_DECODE_LOOP);
+    // ---- step 0: the prompts (prefix run, or one more position when the cache already holds them); next token stays in g_next
+    {
+        const int rc = decode_step_device(c, tokens, token_offsets, rules, vocab_mask, opts, probe_prob != nullptr && opts->probe_token >= 0);
+        if (rc) return rc;
+    }
+    { const int rc = decode_incremental_reserve(c, w, n); if (rc) return rc; }
+    const int64_t Vp = div_up(V, 128) * 128;
+    // ---- device-resident loop state
+    const size_t n_state_ints = (size_t)n * T_cap + 3 * (size_t)n + (size_t)n * max_new + 8 + (size_t)max_new;
+    PCE_HIP(c, w->g_loop.reserve(sizeof(int) * n_state_ints + sizeof(float) * (size_t)n * max_new + 256));
+    int *tok_table = w->g_loop.as<int>(), *len = tok_table + (size_t)n * T_cap, *ended = len + n, *sb = ended + n, *out_tok = sb + n,
+        *ctr = out_tok + (size_t)n * max_new, *n_ended = ctr + 8;
+    float *out_lp = reinterpret_cast<float *>(n_ended + max_new);
+    std::vector<int> h_tab((size_t)n * T_cap, 0), h_len((size_t)n), h_sb((size_t)n), ct((size_t)8 * n, 0);
+    for (int i = 0; i < n; i++) {
+        const int T = token_offsets[i + 1] - token_offsets[i];
+        memcpy(&h_tab[(size_t)i * T_cap], &tokens[token_offsets[i]], sizeof(int) * (size_t)T);
+        h_len[(size_t)i] = T; h_sb[(size_t)i] = opts->sample_begin ? opts->sample_begin[i] : opts->sample_begin_all;
+        ct[(size_t)n + i] = i; ct[(size_t)2 * n + i] = 1; ct[(size_t)3 * n + i] = i * T_cap; ct[(size_t)5 * n + i] = i * W_CTX; ct[(size_t)6 * n + i] = W_CTX;
+    }
+    PCE_HIP(c, hipMemsetAsync(ended, 0, sizeof(int) * (n_state_ints - (size_t)n * T_cap - (size_t)n) + sizeof(float) * (size_t)n * max_new, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(tok_table, h_tab.data(), sizeof(int) * h_tab.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(len, h_len.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(sb, h_sb.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(w->g_c_tab.p, ct.data(), sizeof(int) * ct.size(), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));                 // (the host vectors are done with; the ONE upload of the window)
+    int *CT = w->g_c_tab.as<int>();
+    const int *next = w->g_next.as<int>();
+    const float *next_lp = reinterpret_cast<const float *>(w->g_next.as<int>() + n);
+    auto advance = [&]() {
+        hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(256), 0, c->stream, n, T_cap, (int)rules->eot, (int)max_new, tok_table, len, next, next_lp, CT, ended,
+                           out_tok, out_lp, ctr, n_ended);
+    };
+    auto all_ended = [&](int step, bool *yes) -> int {
+        int cnt = 0;
+        PCE_HIP(c, hipMemcpyAsync(&cnt, n_ended + step, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PCE_HIP(c, hipStreamSynchronize(c->stream));
+        *yes = cnt >= n;
+        return PCE_OK;
+    };
+    advance();
+    int steps = 1;
+    bool stop = false;
+    DecRules R{rules->eot, rules->timestamp_begin, V, (int)Vp, opts->sample_begin_all, rules->max_initial_timestamp_index, opts->temperature, opts->seed_lo,
+               opts->seed_hi, -1};
+    if (max_new > 1) { const int rc = all_ended(0, &stop); if (rc) return rc; }
+    while (!stop && steps < max_new) {
+        decode_incremental_launches(c, w, n, CT, ended);
+        PCE_HIP(c, hipMemsetAsync(w->g_logits.p, 0, sizeof(float) * (size_t)n * (size_t)Vp, c->stream));
+        launch_gemm<EPI_RESID_F32>(c, w->g_lastln.as<bf16>(), d, 0, w->g_emb_bf16.as<bf16>(), n, (int)Vp, d, nullptr, w->g_logits.as<float>(), Vp, 0, 1);
+        hipLaunchKernelGGL(k_decode_rules, dim3((unsigned)n), dim3(256), 0, c->stream, w->g_logits.as<float>(), tok_table, len, T_cap,
+                           w->g_mask.as<unsigned char>(), R, sb, w->g_next.as<int>(), reinterpret_cast<float *>(w->g_next.as<int>() + n),
+                           static_cast<float *>(nullptr));
+        advance();
+        steps++;
+        if (steps % check_every == 0 && steps < max_new) { const int rc = all_ended(steps - 1, &stop); if (rc) return rc; }
+    }
+    PCE_HIP(c, hipGetLastError());
+    // ---- the ONE download of the window
+    std::vector<int> h_out((size_t)n * max_new);
+    std::vector<float> h_lp((size_t)n * max_new);
+    PCE_HIP(c, hipMemcpyAsync(h_out.data(), out_tok, sizeof(int) * h_out.size(), hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(h_lp.data(), out_lp, sizeof(float) * h_lp.size(), hipMemcpyDeviceToHost, c->stream));
     if (probe_prob && opts->probe_token >= 0)
         PCE_HIP(c, hipMemcpyAsync(probe_prob, w->g_next.as<int>() + 2 * n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++)
+        for (int sidx = 0; sidx < max_new; sidx++) {
+            // steps that never ran read as "already ended": end-of-text with a zero log-probability, what further steps would have produced
+            out_tokens[(size_t)i * max_new + sidx] = sidx < steps ? h_out[(size_t)i * max_new + sidx] : rules->eot;
+            if (out_logprobs) out_logprobs[(size_t)i * max_new + sidx] = sidx < steps ? h_lp[(size_t)i * max_new + sidx] : 0.f;
+        }
+    *out_steps = steps;
+    w->g_cache_len = -1;                                         // the host's copy of the cached prefixes is stale: the next host-driven step re-runs its prefixes
     return PCE_OK;
 }
 

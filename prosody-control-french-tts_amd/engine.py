@@ -109,7 +109,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex",
+           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_selftest_attention", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
@@ -159,6 +159,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_whisper_decode_step.argtypes = [vp, vp, vp, i32, C.POINTER(WhisperDecodeRules), vp, vp, vp]
     lib.pce_whisper_decode_step_ex.argtypes = [vp, vp, vp, C.POINTER(WhisperDecodeRules), vp, C.POINTER(WhisperDecodeOpts), vp, vp, vp]
+    lib.pce_whisper_decode_loop.argtypes = [vp, vp, vp, C.POINTER(WhisperDecodeRules), vp, C.POINTER(WhisperDecodeOpts), i32, i32, vp, vp, vp, vp]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
@@ -547,6 +548,30 @@ class ProsodyEngine:
         self._check(self._lib.pce_whisper_decode_step_ex(self._ctx, toks.ctypes.data, off.ctypes.data, C.byref(rules), vm.ctypes.data, C.byref(opts),
                                                          nxt.ctypes.data, lp.ctypes.data, pr.ctypes.data if pr is not None else None))
         return nxt, lp, pr
+
+    def whisper_decode_loop(self, token_lists, sample_begin, eot: int, timestamp_begin: int, vocab_mask, max_new: int,
+                            max_initial_timestamp_index=None, temperature: float = 0.0, seed: int = 0, probe_token: int = -1,
+                            no_cache: bool = False, check_every: int = 4):
+        """The free-running loop on the device: prompts up once, at most ``max_new`` steps, results down once (the host only reads an
+        "ended" counter every ``check_every`` steps).  -> (tokens int32 [clips][steps run], log-probabilities float32 [clips][steps run],
+        probe float32 [clips] | None): what ``steps run`` consecutive ``whisper_decode_step_ex`` calls return, column by column."""
+        toks = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32) for t in token_lists]), dtype=np.int32)
+        off = np.zeros(len(token_lists) + 1, dtype=np.int32); np.cumsum([len(t) for t in token_lists], out=off[1:])
+        rules = WhisperDecodeRules(int(eot), int(timestamp_begin), -1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index), 0)
+        vm = np.ascontiguousarray(vocab_mask, dtype=np.uint8)
+        n = len(token_lists)
+        sb = None if np.isscalar(sample_begin) else np.ascontiguousarray(sample_begin, dtype=np.int32)
+        if sb is not None and sb.shape != (n,):
+            raise ValueError("sample_begin: one prompt length per sequence")
+        opts = WhisperDecodeOpts(sb.ctypes.data if sb is not None else None, int(sample_begin) if sb is None else 0, float(temperature),
+                                 int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF, int(probe_token), 1 if no_cache else 0)
+        out = np.zeros((n, int(max_new)), dtype=np.int32); lp = np.zeros((n, int(max_new)), dtype=np.float32)
+        pr = np.zeros(n, dtype=np.float32) if probe_token >= 0 else None
+        steps = C.c_int32()
+        self._check(self._lib.pce_whisper_decode_loop(self._ctx, toks.ctypes.data, off.ctypes.data, C.byref(rules), vm.ctypes.data, C.byref(opts),
+                                                      int(max_new), int(check_every), out.ctypes.data, lp.ctypes.data, C.byref(steps),
+                                                      pr.ctypes.data if pr is not None else None))
+        return out[:, :steps.value], lp[:, :steps.value], pr
 
     # ---------------------------------------------------------------- probabilistic YIN (viewers)
     def pyin_run(self, plan, tables):

@@ -128,6 +128,46 @@ def test_decode_step_ex_prompts_probe_and_sampling(engine, model_dir):
     assert abs(np.mean(many == k) - p[k]) <= 4 * np.sqrt(p[k] * (1 - p[k]) / 300) + 0.03
 
 
+def test_device_resident_decode_loop_equals_the_host_driven_loop(engine, model_dir):
+    """pce_whisper_decode_loop (prompts up once, tables of every later step kept on the device, results down once) against the loop
+    it replaces (one pce_whisper_decode_step_ex round trip per step): the same tokens and the same log-probabilities, step by step,
+    for prompts of different lengths, greedy and at a temperature (the sampling keys are (seed, clip, position) in both), with a
+    sequence that starts out ended, and when the loop stops early because every sequence has produced end-of-text."""
+    clips = [synth.synth_clip(i, seconds=3.0) for i in range(4)]
+    model, tk, tdims, dec = _encode_clips(engine, model_dir, clips)
+    rules = tk.decoding_rules()
+    V = tdims["n_vocab"]
+    sot = list(tk.sot_sequence())
+    prev = tk.encode(" bonjour le monde")
+    prompts = [sot, [tk.sot_prev] + prev + sot, [tk.sot_prev] + prev[:2] + sot, sot]
+    begins = [len(p) for p in prompts]
+    for temp, seed, active in [(0.0, 0, None), (0.7, 11, None), (0.0, 0, [True, False, True, True])]:
+        host = DEC.decode_batch(engine, V, prompts, begins, rules, 14, temperature=temp, seed=seed, active=active, device_loop=False)
+        dev = DEC.decode_batch(engine, V, prompts, begins, rules, 14, temperature=temp, seed=seed, active=active, device_loop=True)
+        assert dev[0] == host[0], (temp, active)
+        for a, b in zip(dev[1], host[1]):
+            assert np.allclose(a, b, rtol=0, atol=2e-3)          # (the streaming single-query attention sums in fp32 where the MFMA kernel rounds P to bf16)
+        assert np.allclose(dev[2], host[2], atol=2e-2)
+        if active:
+            assert dev[0][1] == [] and dev[2][1] == 0.0
+    # raw entry point: column s equals the s-th host-driven step; steps that did not run read as end-of-text
+    mask = DEC.vocab_mask(V, rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    toks, lps, _ = engine.whisper_decode_loop(prompts, begins, rules["eot"], rules["timestamp_begin"], mask, 9, rules["max_initial_timestamp_index"], check_every=2)
+    seqs = [list(p) for p in prompts]
+    for step in range(toks.shape[1]):
+        nxt, lp, _ = engine.whisper_decode_step_ex(seqs, begins, rules["eot"], rules["timestamp_begin"], mask, rules["max_initial_timestamp_index"])
+        assert np.array_equal(nxt, toks[:, step]), step
+        for s_, t in zip(seqs, nxt):
+            s_.append(int(t))
+    # every sequence already ended: ONE step, all end-of-text
+    ended = [p + [rules["eot"]] for p in prompts]
+    toks, lps, _ = engine.whisper_decode_loop(ended, begins, rules["eot"], rules["timestamp_begin"], mask, 12, rules["max_initial_timestamp_index"])
+    assert toks.shape[1] == 1 and (toks == rules["eot"]).all() and (lps == 0).all()
+    # a prompt that leaves no room for max_new tokens is refused, not truncated
+    with pytest.raises(Exception):
+        engine.whisper_decode_loop(prompts, begins, rules["eot"], rules["timestamp_begin"], mask, tdims["n_text_ctx"], rules["max_initial_timestamp_index"])
+
+
 # ----------------------------------------------------------------------------------------------------- transcription flow
 def test_transcribe_batch_invariants(engine, model_dir):
     """Free-running flow on a 4 s, a 33 s (two windows) and a 0.3 s clip: result shape of whisper_timestamped, times inside the
@@ -138,7 +178,14 @@ def test_transcribe_batch_invariants(engine, model_dir):
     long_clip = np.concatenate([synth.synth_clip(10 + k, seconds=3.0) for k in range(11)])
     clips = [synth.synth_clip(1, seconds=4.0), long_clip, (rng.standard_normal(4800) * 3000).astype(np.int16)]
     opts = TR.TranscribeOptions(sample_len=24, logprob_threshold=None, no_speech_threshold=None, compression_ratio_threshold=None)
-    res = TR.transcribe_batch(engine, model, tk, clips, opts, logging.getLogger("t"))
+    class _Catch(logging.Handler):
+        def __init__(self): super().__init__(); self.msgs = []
+        def emit(self, record): self.msgs.append((record.levelno, record.getMessage()))
+    lg = logging.getLogger("t"); catch = _Catch(); lg.addHandler(catch)
+    res = TR.transcribe_batch(engine, model, tk, clips, opts, lg)
+    lg.removeHandler(catch)
+    # the one option of the reference's call the engine cannot honour is announced at WARNING level, every call
+    assert any(lv >= logging.WARNING and "detect_disfluencies" in m for lv, m in catch.msgs)
     assert len(res) == 3
     for r, c in zip(res, clips):
         dur = len(c) / 16000.0
