@@ -120,7 +120,8 @@ class WhisperTranscriber:
     def engine(self) -> ProsodyEngine:
         if self._engine is None:
             dev = str(self.device)
-            self._engine = get_default_engine(int(dev.split(":")[1]) if ":" in dev else 0)
+            # "cuda:3" names the device; a bare "cuda" under a one-process-per-GPU launcher is this rank's own GPU
+            self._engine = get_default_engine(int(dev.split(":")[1]) if ":" in dev else int(os.environ.get("LOCAL_RANK", "0")))
         return self._engine
 
     def load_model(self) -> None:
@@ -365,6 +366,16 @@ def main(audio_path, out_path, whisper_model="medium", device=None, logger=None)
         if N == 0:
             logger.warning(f"Aucun fichier .wav trouvé dans {audio_path}")
             sys.exit(0)
+        # one process per GPU (torch.distributed initialised by the launcher): files are independent, so rank r takes a contiguous
+        # block of the SORTED names and writes those files' outputs; nothing is exchanged (no collective on this step)
+        from .. import shard
+        rank, world = shard.rank_world()
+        if world > 1:
+            names = sorted(names)
+            lo, hi = shard.shard_range(N, rank, world)
+            names = names[lo:hi]
+            N = len(names)
+            logger.info(f"rank {rank}/{world}: fichiers {lo}..{hi - 1}")
         OP = os.path.join(out_path + "_transcription")
         os.makedirs(OP, exist_ok=True)
         textgrid_dir = out_path
@@ -437,6 +448,10 @@ def main(audio_path, out_path, whisper_model="medium", device=None, logger=None)
                 with open(os.path.join(OP, f"{n}.txt"), "w", encoding="utf-8") as f:
                     f.write("...")
 
+        if world > 1:
+            shard.barrier()                                                  # every rank's TextGrids exist before the folders are matched
+            if rank != 0:
+                return
         base_path = os.path.dirname(audio_path)
         if "_microsoft" in base_path:
             natural_dir = os.path.join(os.path.dirname(base_path), os.path.basename(base_path).replace("_microsoft", ""), "WhisperTS_textgrid_files")

@@ -178,12 +178,15 @@ class EngineMeasurements(BatchedMeasurements, MeasurementSource):
     file's rate for natural and synthetic files alike (Code/audioPipeline.py:372), the syntagme-level numbers a meter at
     the segment's own natural file's rate (:493)."""
 
-    def __init__(self, engine: ProsodyEngine, files: Dict[Tuple[str, str], Path], pitch_floor=150.0, pitch_ceiling=600.0):
+    def __init__(self, engine: ProsodyEngine, files: Dict[Tuple[str, str], Path], pitch_floor=150.0, pitch_ceiling=600.0,
+                 first_nat_rate: Optional[int] = None):
         BatchedMeasurements.__init__(self, engine, pitch_floor, pitch_ceiling)
         for key, path in files.items():
             self.add_file(key, path)
         nat = sorted((k for k in self.rate_of if k[0] == "nat"), key=lambda k: segment_sort_key(k[1]))
-        self.first_nat_rate = self.rate_of[nat[0]] if nat else 0          # the segment-level meter (:372)
+        # the segment-level meter (:372) is built at the rate of the voice's FIRST natural file; a rank that holds only a block of
+        # the voice is told that rate (``first_nat_rate``), it does not follow from the rank's own files
+        self.first_nat_rate = int(first_nat_rate) if first_nat_rate else (self.rate_of[nat[0]] if nat else 0)
 
     def _meter_rate(self, segment, t1) -> int:
         if t1 is None:
@@ -293,7 +296,10 @@ class AudioPipeline:
         self.whisper_device = cfg.get("whisper_device", "cuda")
         self.whisper_model = cfg.get("whisper_model", "turbo")
         self.settings = ProsodySettings.from_config(cfg.get("prosody_settings", {}))
-        self.device_index = int(str(self.whisper_device).split(":")[1]) if ":" in str(self.whisper_device) else 0
+        import os
+        # "cuda:3" names the device; a bare "cuda" under a one-process-per-GPU launcher means this rank's own GPU (LOCAL_RANK)
+        self.device_index = (int(str(self.whisper_device).split(":")[1]) if ":" in str(self.whisper_device)
+                             else int(os.environ.get("LOCAL_RANK", "0")))
         self._engine, self._nlp = engine, nlp
         self.results_dir.mkdir(parents=True, exist_ok=True)
         wanted = cfg.get("steps_to_run") or STEP_NAMES
@@ -323,8 +329,34 @@ class AudioPipeline:
             files[("syn", w.stem)] = self.raw_audio_dir / f"{w.stem}.wav"
             tg = read_textgrid(self.textgrid_dir / f"{w.stem}.TextGrid")
             segments.append(SegmentInput(w.stem, tg.tiers[0].intervals))
-        em = EngineMeasurements(self._get_engine(), files)
         tagger = SsmlTagger(self.settings, self.azure_voice, nlp=self._nlp)
+        from . import shard
+        rank, world = shard.rank_world()
+        if world > 1 or self.cfg.get("force_sharded_path"):
+            # One process per GPU (torch.distributed initialised by the launcher): this rank decodes, uploads and measures only its
+            # contiguous block of the segment-sorted list; ONE all-gather of the per-segment / per-syntagme records (RCCL over xGMI
+            # under the nccl backend); baselines, adjustments, the EMA over all syntagmes and the SSML strings on every rank
+            # (Code/audioPipeline.py:364-424, :592-602).  Rank 0 writes the three tables.
+            lo, hi = shard.shard_range(len(segments), rank, world)
+            mine = segments[lo:hi]
+            local_files = {k: v for k, v in files.items() if k[1] in {sg.name for sg in mine}}
+            first_rate = None
+            try:
+                first_rate = H.decode_wav(wavs[0])[0]                        # the voice's first natural file fixes the segment-level meter (:372)
+            except H.CouldntDecodeError:
+                pass
+            em = EngineMeasurements(self._get_engine(), local_files, first_nat_rate=first_rate)
+            planner = _Planner(em)
+            tagger.segment_statistics(mine, planner); tagger.syntagme_measurements(mine, planner)     # pass 1 over the local block: collect the queries
+            em.run()
+            res = tagger.run_sharded(segments, em, rank, world, shard.allgather_records)
+            if rank == 0:
+                res.bdd_ssml.to_csv(self.bdd_ssml_csv, index=False)
+                res.bdd_syntagme_ssml.to_csv(self.bdd_syntagme_ssml_csv, index=False)
+                res.bdd_syntagme_for_synth.to_csv(self.bdd_syntagme_synth_csv, index=False)
+            shard.barrier()                                                  # the tables exist when any rank returns
+            return res
+        em = EngineMeasurements(self._get_engine(), files)
         tagger.run(segments, _Planner(em))         # pass 1: collect every query (they depend on the TextGrids only)
         em.run()                                   # three batched GPU passes
         res = tagger.run(segments, em)             # pass 2: the real numbers

@@ -233,7 +233,7 @@ __device__ __forceinline__ void gelu_exact8(float (&x)[8])
 // LDS address when reading (the same involution on both sides).
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-constexpr int G_THREADS = 512, G_STAGES = 2;
+constexpr int G_THREADS = 512;
 constexpr int G_TLD = G_BN + 4;           // fp32 epilogue tile row (pad keeps the accumulator scatter conflict-free)
 
 // one operand tile (128 rows x 64 k): 16 wave-instructions of 1 KiB (8 rows each); 8 waves -> 2 each
@@ -347,8 +347,12 @@ __device__ __forceinline__ void gemm_store_tile(const float *tile, int tid, int 
 // while tile kt is multiplied, tiles kt+1 and kt+2 are in flight as LDS-DMA (4 instructions per wave and
 // tile), so a tile has two full K-steps to arrive.  The barrier is a raw s_barrier behind a COUNTED
 // s_waitcnt vmcnt(4): __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring.
-template <int EPI>
-__global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
+// G_STAGES = 2: two workgroups per CU cover each other's waits (big grids).  G_STAGES = 4 (round 3): the few-row launches of an
+// incremental decoding step (M = clips: 2 x N/128 workgroups on 256 CUs) are alone on their CU and each K-step waited out a full
+// L2 / HBM round trip (12 K-steps x 1.5 us = the 24 us such a launch took); with three tiles in flight the K loop runs at the
+// DMA issue rate instead.
+template <int EPI, int G_STAGES = 2>
+__global__ __launch_bounds__(G_THREADS, G_STAGES == 2 ? 4 : 2) void k_gemm_bf16(const bf16 *__restrict__ A, int64_t lda, int64_t a_batch,
                                                         const bf16 *__restrict__ B, int M, int N, int K,
                                                         const float *__restrict__ bias, void *__restrict__ Cv, int64_t ldc, int64_t c_batch,
                                                         const float *__restrict__ pos, int pos_T, int v_col0, int vt_sp, int sn_tiles, int sm_tiles, unsigned long long *trace)
@@ -388,22 +392,24 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
     const int fr = lane & 15, fq = lane >> 4;
     const int nk = K / G_BK;
     constexpr int STAGE = 2 * G_BM * G_BK;
-    stage_tile(A, lda, m0, M - 1, 0, smem, wv, lane);
-    stage_tile(B, K, n0, N - 1, 0, smem + G_BM * G_BK, wv, lane);
-    if (G_STAGES > 2 && nk > 1) {
-        stage_tile(A, lda, m0, M - 1, G_BK, smem + STAGE, wv, lane);
-        stage_tile(B, K, n0, N - 1, G_BK, smem + STAGE + G_BM * G_BK, wv, lane);
+    // prologue: tiles 0 .. G_STAGES - 2 (every tile is 4 DMA instructions per wave; a tile past the end of K is issued anyway -- the last
+    // tile again, into a slot nobody reads -- so that the counted waits below are the same in every iteration)
+#pragma unroll
+    for (int t = 0; t < G_STAGES - 1; t++) {
+        const int tt = t < nk ? t : nk - 1;
+        stage_tile(A, lda, m0, M - 1, tt * G_BK, smem + t * STAGE, wv, lane);
+        stage_tile(B, K, n0, N - 1, tt * G_BK, smem + t * STAGE + G_BM * G_BK, wv, lane);
     }
     for (int kt = 0; kt < nk; kt++) {
         const bf16 *sA = smem + (kt % G_STAGES) * STAGE, *sB = sA + G_BM * G_BK;
-        // tile kt has landed once at most the 4 youngest DMAs of this wave (tile kt+1) are outstanding
-        if (G_STAGES > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kt has landed once at most the DMAs of the G_STAGES - 2 younger tiles of this wave are outstanding
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (((4 * (G_STAGES - 2)) >> 4) << 14) | ((4 * (G_STAGES - 2)) & 15));
         __builtin_amdgcn_s_barrier();
-        if (kt + G_STAGES - 1 < nk) {                        // refill the stage tile kt-1 has just released
+        if (G_STAGES > 2 || kt + G_STAGES - 1 < nk) {        // refill the stage tile kt-1 has just released (deep ring: always, see the prologue)
+            const int tn = kt + G_STAGES - 1 < nk ? kt + G_STAGES - 1 : nk - 1;
             bf16 *nA = smem + ((kt + G_STAGES - 1) % G_STAGES) * STAGE;
-            stage_tile(A, lda, m0, M - 1, (kt + G_STAGES - 1) * G_BK, nA, wv, lane);
-            stage_tile(B, K, n0, N - 1, (kt + G_STAGES - 1) * G_BK, nA + G_BM * G_BK, wv, lane);
+            stage_tile(A, lda, m0, M - 1, tn * G_BK, nA, wv, lane);
+            stage_tile(B, K, n0, N - 1, tn * G_BK, nA + G_BM * G_BK, wv, lane);
         }
 #pragma unroll
         for (int kk = 0; kk < G_BK; kk += 32) {
@@ -428,6 +434,7 @@ __global__ __launch_bounds__(G_THREADS, 4) void k_gemm_bf16(const bf16 *__restri
     // epilogue.  The accumulator layout (col = lane & 15, row = (lane >> 4) * 4 + reg) would store 2-byte
     // elements 32 B at a time; measured, such an epilogue cost more than the whole K loop.  The tile
     // goes through LDS instead (the operand ring is free now) and leaves as full 256-B row segments.
+    if (G_STAGES > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus refills of the deep ring must have landed before the ring is reused
     __builtin_amdgcn_s_barrier();                           // every wave is done reading the operand stages
     float *tile = reinterpret_cast<float *>(smem);           // [128][G_TLD] fp32 = 66 KiB
 #pragma unroll
@@ -1130,10 +1137,13 @@ struct Attn1Args {
     const int *skip;                          // per clip or null
     bf16 *out; int64_t out_ld;                // out + c * out_ld + head * 64
 };
-__global__ __launch_bounds__(256) void k_cross_attn1(Attn1Args A)
+// 128 threads: 16 workgroups fit a CU, so the 3 072 (clip, head) pairs of 256 clips at Whisper-small size are ONE resident round
+// (with 256 threads 2 048 run at a time and the second round leaves half the chip idle)
+constexpr int A1_T = 128, A1_W = A1_T / 64;
+__global__ __launch_bounds__(A1_T) void k_cross_attn1(Attn1Args A)
 {
     __shared__ float sp[1536];
-    __shared__ float red[8];
+    __shared__ float red[2 * A1_W];
     __shared__ float so[64];
     const int head = blockIdx.x, clip = blockIdx.y;
     if (A.skip && A.skip[clip]) return;
@@ -1148,12 +1158,12 @@ __global__ __launch_bounds__(256) void k_cross_attn1(Attn1Args A)
     }
     const bf16 *kb = A.k + (int64_t)A.k_row0[clip] * A.k_ld + head * 64 + ch * 8;
     constexpr int U = 8;
-    for (int base = wv * 8; base < Sk; base += 32 * U) {
+    for (int base = wv * 8; base < Sk; base += 8 * A1_W * U) {
         bf16x8 kv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int r = base + u * 32 + g;
-            kv[u] = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)(r < Sk ? r : Sk - 1) * A.k_ld);
+            const int r = base + u * 8 * A1_W + g;
+            kv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(kb + (int64_t)(r < Sk ? r : Sk - 1) * A.k_ld));      // read once per step: streamed
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -1161,42 +1171,48 @@ __global__ __launch_bounds__(256) void k_cross_attn1(Attn1Args A)
 #pragma unroll
             for (int e = 0; e < 8; e++) d = fmaf((float)kv[u][e], qf[e], d);
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            const int r = base + u * 32 + g;
+            const int r = base + u * 8 * A1_W + g;
             if (ch == 0 && r < Sk) sp[r] = d;
         }
     }
     __syncthreads();
     float m = -3.0e38f;
-    for (int t = tid; t < Sk; t += 256) m = fmaxf(m, sp[t]);
+    for (int t = tid; t < Sk; t += A1_T) m = fmaxf(m, sp[t]);
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) red[wv] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+#pragma unroll
+    for (int u = 1; u < A1_W; u++) m = fmaxf(m, red[u]);
     float sum = 0.f;
     const int Sp = (Sk + 511) & ~511;                            // p is read in 512-key pieces: zero beyond the last key
-    for (int t = tid; t < Sp; t += 256) {
+    for (int t = tid; t < Sp; t += A1_T) {
         const float pv = t < Sk ? __expf(sp[t] - m) : 0.f;
         sp[t] = pv; sum += pv;
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) red[4 + wv] = sum;
+    if (lane == 0) red[A1_W + wv] = sum;
     __syncthreads();
-    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    float tot = red[A1_W];
+#pragma unroll
+    for (int u = 1; u < A1_W; u++) tot += red[A1_W + u];
+    const float inv = 1.0f / tot;
     const int np = Sp >> 9;                                      // 1..3 pieces
     float pr[3][8];
 #pragma unroll
     for (int j = 0; j < 3; j++)
 #pragma unroll
         for (int e = 0; e < 8; e++) pr[j][e] = j < np ? sp[j * 512 + lane * 8 + e] : 0.f;
-    const bf16 *vb = A.vt + (int64_t)clip * A.vt_clip + (int64_t)(head * 64 + wv * 16) * A.vt_sp + lane * 8;
-#pragma unroll
-    for (int r4 = 0; r4 < 16; r4 += 4) {
+    constexpr int RW = 64 / A1_W;                                // V^T rows (output dims) per wave
+    const bf16 *vb = A.vt + (int64_t)clip * A.vt_clip + (int64_t)(head * 64 + wv * RW) * A.vt_sp + lane * 8;
+#pragma unroll 2
+    for (int r4 = 0; r4 < RW; r4 += 4) {
         bf16x8 vv[4][3];
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                if (j < np) vv[r][j] = *reinterpret_cast<const bf16x8 *>(vb + (int64_t)(r4 + r) * A.vt_sp + j * 512);
+                if (j < np) vv[r][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(vb + (int64_t)(r4 + r) * A.vt_sp + j * 512));
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             float a = 0.f;
@@ -1206,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_cross_attn1(Attn1Args A)
 #pragma unroll
                     for (int e = 0; e < 8; e++) a = fmaf(pr[j][e], (float)vv[r][j][e], a);
             for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-            if (lane == 0) so[wv * 16 + r4 + r] = a * inv;
+            if (lane == 0) so[wv * RW + r4 + r] = a * inv;
         }
     }
     __syncthreads();
@@ -1729,8 +1745,12 @@ void launch_gemm(pce_ctx *c, const bf16 *A, int64_t lda, int64_t a_batch, const 
     }
     {
         KernelTimer kt(c, PCE_K_GEMM128, nullptr, 2.0 * M * (double)N * K * batch);
-        hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
-                           v_col0, vt_sp, sn, sm, g_gemm_trace);
+        if ((int64_t)M * batch <= 1024 && K >= 4 * G_BK && !want_trace)      // a few rows (incremental decoding step): few workgroups, each alone on its CU
+            hipLaunchKernelGGL((k_gemm_bf16<EPI, 4>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
+                               v_col0, vt_sp, sn, sm, g_gemm_trace);
+        else
+            hipLaunchKernelGGL((k_gemm_bf16<EPI>), grid, dim3(G_THREADS), 0, c->stream, A, lda, a_batch, B, M, N, K, bias, C, ldc, c_batch, pos, pos_T,
+                               v_col0, vt_sp, sn, sm, g_gemm_trace);
     }
     if (want_trace) {
         const size_t nblk = (size_t)grid.x * grid.y;
@@ -2441,7 +2461,7 @@ static void decode_incremental_launches(pce_ctx *c, WhisperState *w, int n, cons
             a.q = q; a.q_ld = q_ld; a.k = k; a.k_ld = k_ld; a.vt = vt; a.vt_clip = vt_clip; a.vt_sp = vt_sp; a.k_row0 = k0; a.k_len = kl; a.skip = ended;
             a.out = w->g_c_attn.as<bf16>(); a.out_ld = d;
             KernelTimer kt(c, PCE_K_CROSS_ATTN1);
-            hipLaunchKernelGGL(k_cross_attn1, dim3((unsigned)H, (unsigned)n), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(k_cross_attn1, dim3((unsigned)H, (unsigned)n), dim3(A1_T), 0, c->stream, a);
             return;
         }
         AttnArgs a{};

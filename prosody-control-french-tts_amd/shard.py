@@ -25,6 +25,26 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_world():
+    """(rank, world) of the initialised ``torch.distributed`` process group; (0, 1) when there is none -- the product entry
+    points (``AudioPipeline.measure_prosody_and_build_ssml``, ``Aligners.use_whisper_timestamped.main``) shard whenever the
+    launcher (``torchrun`` / ``bench.py --gpus N`` style, one process per GPU) has initialised one, and run as before otherwise."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:                                                    # noqa: BLE001  (torch absent: single process)
+        pass
+    return 0, 1
+
+
+def barrier():
+    """No-op without a process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def allgather_records(local: np.ndarray, counts=None, device=None) -> np.ndarray:
     """All-gather ragged per-rank record blocks ``[n_local, width]`` (float64) into ``[n_total, width]`` in rank order
     with ONE collective (``all_gather_into_tensor``; RCCL over xGMI when the backend is "nccl").

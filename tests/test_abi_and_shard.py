@@ -151,6 +151,109 @@ def test_sharded_tagger_reproduces_reference_csvs_gloo_world2(tmp_path):
         assert p.returncode == 0, o
 
 
+_PIPELINE_WORKER = r'''
+import os, sys, wave
+import numpy as np
+sys.path.insert(0, sys.argv[3]); sys.path.insert(0, os.path.join(sys.argv[3], "tests"))
+import torch.distributed as dist
+from pathlib import Path
+from oracle import oracle as O                        # (tests may: the stub engine below answers from the CPU oracle)
+from prosody_control_french_tts_amd import engine as E, shard, synth, tagger as T, textgrid_io as TG
+from prosody_control_french_tts_amd.audio_pipeline import AudioPipeline
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+base = Path(sys.argv[5])
+
+class OracleEngine:
+    """What EngineMeasurements calls on a ProsodyEngine, answered on the CPU; counts what this rank uploads."""
+    uploaded = 0
+    def upload(self, clips, rate):
+        self.clips, self.rate, self.meter = [np.asarray(c) for c in clips], rate, 0
+        OracleEngine.uploaded += len(clips)
+    def lufs_set_meter_rate(self, r):
+        self.meter = r
+    def pitch(self, slices, params, want_f0=False):
+        out = np.zeros(len(slices), dtype=E.SUMMARY_DTYPE)
+        for i, s in enumerate(slices):
+            z = self.clips[s["clip"]][s["begin"]:s["end"]].astype(np.float64) / 32768.0
+            try:
+                f = O.pitch_ac(z, 1.0 / self.rate, float(s["x1"]), O.praat_params(150.0, 600.0))["f0"]
+            except O.PraatError:
+                out[i]["status"] = E.SLICE_TOO_SHORT; continue
+            v = f[f > 0]
+            out[i]["median_f0"] = float(np.median(v)) if v.size else 0.0
+        return {"summary": out}
+    def lufs(self, slices):
+        vals, st = np.zeros(len(slices)), np.zeros(len(slices), dtype=np.int32)
+        for i, s in enumerate(slices):
+            try:
+                vals[i] = O.lufs_numpy(self.clips[s["clip"]][s["begin"]:s["end"]].astype(float), self.meter or self.rate)
+            except ValueError:
+                st[i] = E.SLICE_TOO_SHORT
+        return vals, st
+
+def wav(path, pcm, rate):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate); w.writeframes(pcm.astype("<i2").tobytes())
+
+# a voice of 5 segments (rank 0 writes it, everybody reads it)
+voice = base / "Data" / "v1"; raw = base / "Data" / "v1_raw" / "audio"
+if rank == 0:
+    (voice / "audio").mkdir(parents=True); (voice / "WhisperTS_textgrid_files").mkdir(); raw.mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    words = ["Bonjour", "le", "monde,", "voila", "une", "phrase.", "Tres", "longue", "ici?", "oui", "de", "la", "mer!"]
+    for k in range(5):
+        rate = 16000
+        nat = synth.synth_clip(40 + k, seconds=1.6)
+        syn = (np.roll(nat, 500).astype(np.int32) * 3 // 4).astype(np.int16)[: int(len(nat) * 0.9)]
+        wav(voice / "audio" / f"segment_ph{k + 1}.wav", nat, rate); wav(raw / f"segment_ph{k + 1}.wav", syn, rate)
+        t, ivs = 0.0, []
+        while t < 1.3:
+            d = float(np.round(rng.uniform(0.12, 0.3), 3)); ivs.append((t, t + d, str(rng.choice(words)))); t += d
+            if rng.random() < 0.4:
+                d = float(np.round(rng.choice([0.06, 0.16, 0.25]), 3)); ivs.append((t, t + d, " ")); t += d
+        TG.write_textgrid(TG.TextGrid([TG.IntervalTier("words", ivs)], 0.0, t), voice / "WhisperTS_textgrid_files" / f"segment_ph{k + 1}.TextGrid")
+cfg = {"data_dir": "Data", "out_dir": "Out", "azure_voice_name": "fr-FR-HenriNeural", "whisper_device": "cuda",
+       "prosody_settings": {"baseline_window": 3, "smoothing_alpha": 0.2, "max_jump_percent": 8}, "steps_to_run": ["Measure & Build SSML"]}
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dist.barrier()
+calls = []
+_orig = dist.all_gather_into_tensor
+def _counting(*a, **k):
+    calls.append(1); return _orig(*a, **k)
+dist.all_gather_into_tensor = _counting
+ap = AudioPipeline("v1", cfg, base=base, engine=OracleEngine())
+res = ap.measure_prosody_and_build_ssml()                      # torch.distributed is initialised: the sharded path
+assert len(calls) == 1, calls                                  # ONE collective
+n_up = OracleEngine.uploaded
+assert n_up == 2 * (3 if rank == 0 else 2), n_up               # only this rank's block was decoded and uploaded (nat + syn files)
+sharded = {p.name: p.read_text(encoding="utf-8") for p in (ap.bdd_ssml_csv, ap.bdd_syntagme_ssml_csv, ap.bdd_syntagme_synth_csv)}
+assert len(res.bdd_syntagme_ssml) == len(res.rows) > 5
+dist.barrier(); dist.destroy_process_group()
+# the same step without a process group (single rank, unsharded path) writes the same three files, text for text
+cfg2 = dict(cfg, out_dir=f"Out_single_{rank}")
+ap2 = AudioPipeline("v1", cfg2, base=base, engine=OracleEngine())
+ap2.measure_prosody_and_build_ssml()
+for p in (ap2.bdd_ssml_csv, ap2.bdd_syntagme_ssml_csv, ap2.bdd_syntagme_synth_csv):
+    assert p.read_text(encoding="utf-8") == sharded[p.name], (rank, p.name)
+print("rank", rank, "ok")
+'''
+
+
+def test_audio_pipeline_measure_step_shards_under_torch_distributed_gloo_world2(tmp_path):
+    """The PRODUCT entry point (``AudioPipeline.measure_prosody_and_build_ssml``) under an initialised process group: each rank
+    decodes / uploads / measures only its block of the voice (a stub engine answering from the CPU oracle counts the uploads), ONE
+    all-gather, rank 0 writes the three tables -- text for text what the single-process step writes."""
+    script = tmp_path / "p.py"
+    script.write_text(_PIPELINE_WORKER)
+    port = str(29400 + os.getpid() % 150)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=400)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
 def test_bench_gpus_n_starts_n_ranks_itself():
     """`python bench.py --gpus 2` with no rendezvous in the environment starts two rank processes itself and rank 0
     prints the line with n_gpus = 2 (launcher + exchange on CPU: gloo, no engine)."""
