@@ -162,6 +162,39 @@ def test_measure_and_build_ssml_step_matches_cpu_reference_path(engine, excerpts
         assert got_csv.read_text(encoding="utf-8") == p.read_text(encoding="utf-8")
 
 
+def test_measure_step_through_the_sharded_path_equals_the_unsharded_tables(engine, excerpts, tmp_path):
+    """The path the ranks of a multi-GPU run take (local block planned and uploaded, ``SsmlTagger.run_sharded`` fed by
+    ``EngineMeasurements``, records through ``shard.allgather_records``) at world size 1 on the engine: the three tables equal the
+    unsharded step's, text for text (``force_sharded_path`` is the additive config key that selects it without a process group;
+    the world-2 exchange itself runs under gloo in tests/test_abi_and_shard.py)."""
+    rate, clips = excerpts
+    rng = np.random.default_rng(23)
+    cfg = {"data_dir": "Data", "out_dir": "Out", "azure_voice_name": "fr-FR-HenriNeural", "whisper_device": "cuda:0",
+           "prosody_settings": {"baseline_window": 3, "smoothing_alpha": 0.3, "max_jump_percent": 6}, "steps_to_run": ["Measure & Build SSML"]}
+    voice = tmp_path / "Data" / "v1"
+    (voice / "audio").mkdir(parents=True); (voice / "WhisperTS_textgrid_files").mkdir()
+    raw = tmp_path / "Data" / "v1_raw" / "audio"; raw.mkdir(parents=True)
+    words = ["Bonjour", "le", "monde,", "voilà", "une", "phrase.", "Très", "longue", "ici?", "oui", "de", "la", "mer!"]
+    for name in sorted(clips)[:5]:
+        nat = clips[name]
+        syn = np.clip(np.roll(nat, 300).astype(np.int32) * 2 // 3, -32768, 32767).astype(np.int16)[: int(len(nat) * rng.uniform(0.85, 1.0))]
+        _write_wav(voice / "audio" / name, nat, rate); _write_wav(raw / name, syn, rate)
+        t, ivs = 0.0, []
+        while t < 1.05:
+            d = float(np.round(rng.uniform(0.09, 0.3), 3)); ivs.append((t, t + d, str(rng.choice(words)))); t += d
+            if rng.random() < 0.4:
+                d = float(np.round(rng.choice([0.06, 0.16, 0.25]), 3)); ivs.append((t, t + d, " ")); t += d
+        TG.write_textgrid(TG.TextGrid([TG.IntervalTier("words", ivs)], 0.0, t), voice / "WhisperTS_textgrid_files" / f"{name[:-4]}.TextGrid")
+    plain = AudioPipeline("v1", cfg, base=tmp_path, engine=engine)
+    plain.measure_prosody_and_build_ssml()
+    sharded = AudioPipeline("v1", dict(cfg, out_dir="Out_sharded", force_sharded_path=True), base=tmp_path, engine=engine)
+    res = sharded.measure_prosody_and_build_ssml()
+    assert len(res.rows) > 5
+    for a, b in ((plain.bdd_ssml_csv, sharded.bdd_ssml_csv), (plain.bdd_syntagme_ssml_csv, sharded.bdd_syntagme_ssml_csv),
+                 (plain.bdd_syntagme_synth_csv, sharded.bdd_syntagme_synth_csv)):
+        assert a.read_text(encoding="utf-8") == b.read_text(encoding="utf-8"), a.name
+
+
 def test_legacy_pipeline_modules_on_gpu(engine, excerpts, tmp_path):
     """Legacy ``Code/Pipeline`` API: _calculate_loudness (golden G3, bit-exact), calculate_pitch_segment
     (oracle restatement of the floors-75/100/150/200 geometric-mean rule) and the aligner's gate (golden G4)."""
