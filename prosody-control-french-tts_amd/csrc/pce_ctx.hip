@@ -125,6 +125,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->gemm_wide = getenv("PCE_GEMM_WIDE") ? atoi(getenv("PCE_GEMM_WIDE")) : -1;
     c->gemm_trace = getenv("PCE_GEMM_TRACE") != nullptr;
     c->dbg_pitch_lds_fft = getenv("PCE_PITCH_LDS_FFT") != nullptr;
+    c->pitch_refine_praat = getenv("PCE_PITCH_REFINE") && !strcmp(getenv("PCE_PITCH_REFINE"), "praat");
     c->dbg_pitch_tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) : -1;
     c->dbg_pitch = getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0;
     c->refine_blocks_per_cu = getenv("PCE_K2_BPC") ? atoi(getenv("PCE_K2_BPC")) : 24;

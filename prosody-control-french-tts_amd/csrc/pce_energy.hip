@@ -204,6 +204,10 @@ int pce_energy_run(pce_ctx *c, const pce_slice *slices, int32_t n, int32_t loud_
     if (!c || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
     if (!c->d_pcm) return pce_fail(c, PCE_E_STATE, "no batch uploaded");
     PCE_HIP(c, hipSetDevice(c->device));
+    if (c->lu_reads_en_out) {                                    // a LUFS chain on its side stream reads the peaks of the previous run out of en_out
+        int rc = pce_side_join(c, pce_ctx::SIDE_LUFS); if (rc) return rc;
+        c->lu_reads_en_out = false;
+    }
     if (!c->en_cache.same(slices, n)) {
         c->en_n = -1;
         int st = pce_energy_plan(c, slices, n, c->en_work, c->en_out, &c->en_n_work);

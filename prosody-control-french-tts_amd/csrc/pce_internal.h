@@ -52,6 +52,7 @@ struct pce_ctx {
     bool no_side = false;                // PCE_NO_AUX at pce_create: everything on `stream`
     bool generic_median = false;         // PCE_ALIGN_GENERIC_MEDIAN at pce_create: the insertion-sort median filter for every width
     // debugging / tuning knobs, read once at pce_create (never in a launch path)
+    bool pitch_refine_praat = false;     // PCE_PITCH_REFINE=praat at pce_create: the candidate refinement replays NUMminimize_brent's own iterates (round 1 / 2 behaviour)
     bool dbg_pitch_lds_fft = false; int dbg_pitch_tabs = -1, dbg_pitch = 0, refine_blocks_per_cu = 24;
     bool attn1 = true;                   // PCE_ATTN1=0 at pce_create: incremental decoding steps keep the MFMA attention kernel (one live query per tile) instead of k_cross_attn1
     int attn_mode = 1;                   // PCE_ATTN at pce_create: 1 = k_attention_lean (default), 2 = its exact path only, 0 = k_attention (round 1)
@@ -83,6 +84,7 @@ struct pce_ctx {
     double lu_coef[13] = {0};
     int32_t lu_n = -1;
     int32_t lu_meter_rate = 0;       // pce_lufs_set_meter_rate: 0 = the batch's own rate
+    bool lu_reads_en_out = false;    // the running LUFS chain takes its peaks from pce_energy_run's accumulators (same slices)
     std::vector<int32_t> lu_host_status;
 
     // pitch

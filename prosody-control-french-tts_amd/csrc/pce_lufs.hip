@@ -389,11 +389,18 @@ int pce_lufs_run(pce_ctx *c, const pce_slice *slices, int32_t n)
     // previous batch's result copies), so the pitch kernels launched next run beside it; consumers join first.
     hipStream_t ls = c->stream;
     { int rc = pce_side_begin(c, pce_ctx::SIDE_LUFS, &ls); if (rc) return rc; }
-    int st = pce_energy_launch(c, n, 500, c->lu_n_energy_work, c->lu_en_work, c->lu_en_acc, ls);
-    if (st) return st;
+    // the peaks that normalise the slices (get_lufs divides by max |x|): when pce_energy_run has just covered the SAME slices its
+    // accumulators hold them (the fork above orders this chain behind it): no second pass over the PCM.  pce_energy_run joins this side
+    // stream before it overwrites them (lu_reads_en_out).
+    const bool reuse = c->en_n == n && c->en_cache.same(slices, n);
+    if (!reuse) {
+        int st = pce_energy_launch(c, n, 500, c->lu_n_energy_work, c->lu_en_work, c->lu_en_acc, ls);
+        if (st) return st;
+    }
+    c->lu_reads_en_out = reuse;
     LuCoef k; memcpy(&k, c->lu_coef, sizeof k);
     size_t pstride = 0;
-    const int *peaks = pce_energy_peak_ptr(c->lu_en_acc, &pstride);
+    const int *peaks = pce_energy_peak_ptr(reuse ? c->en_out : c->lu_en_acc, &pstride);
     const int nch = (int)c->lu_n_chunks;
     if (nch > 0) {
         {

@@ -83,6 +83,8 @@ struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
     int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, mode, fpb;
     int o_tw2, o_twN, o_win, o_winR, blob_f64, pcm_span, tabs, rr_half;   // register paths: table blob layout (offsets in doubles)
+    int refine_seeded, pad_;                                              // k_pitch_refine: 1 = Brent's state seeded with the three samples (default), 0 = Praat's own iterates
+    double refine_tol_rel;                                                // ... and the relative stopping tolerance (5e-8; Praat's own: sqrt(eps) = 1.49e-8)
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -964,7 +966,6 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
     items += (size_t)list * list_cap;
     const int ynx = 2 * P.bix + 1;
     const double golden = 1.0 - 0.6180339887498948482045868343656381177203;
-    const double sqrt_epsilon = 1.4901161193847656e-08;
     const double tol = 1e-10;
     auto finish = [&](const RefineItem &item, double xres, double yres) {
         xres -= (double)(P.bix + 1);
@@ -974,10 +975,18 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
             cand[item.frame * 32 + 16 + item.slot] = yres;
         }
     };
-    // Brent's minimiser (Praat NUMminimize_brent on -sinc) as a state machine: every trip of the loop
-    // is ONE function evaluation for each of the wave's eight candidates, and a group whose candidate
-    // has converged fetches its next item at once, so candidates with different iteration counts do not
-    // wait for one another.  The iterates are those of the sequential loop.
+    // Brent's minimiser (Praat NUMimproveMaximum -> NUMminimize_brent on -sinc) as a state machine: every trip of the loop is ONE
+    // function evaluation for each of the wave's eight candidates, and a group whose candidate has converged fetches its next item
+    // at once, so candidates with different iteration counts do not wait for one another.
+    // Round 3: the search no longer replays Praat's iterates, it starts where they end up.  Praat opens with a golden-section point of
+    // [ixmid - 1, ixmid + 1] and needs 10-13 evaluations; here Brent's state is SEEDED with the three samples around the maximum
+    // (x = ixmid, w / v = its neighbours: their function values are the autocorrelation samples themselves, no evaluation), so the
+    // first trial point already is the parabolic estimate and the same safeguarded loop (parabolic step inside the bracket, else
+    // golden section; steps never shorter than the tolerance) closes in 4-6 evaluations.  Both searches end within the stopping
+    // tolerance of the one maximum of the interpolant in the bracket.  Tolerance: Praat stops at sqrt(eps) |x| + tol / 3 ~ 1.5e-8 |x|
+    // (x = 27-107 lags: ~1e-6 lags absolute, i.e. 1.5e-8 RELATIVE in F0); the parity gate is 1e-6 relative, so the stop here is
+    // 5e-8 |x| -- an F0 error of at most ~2e-7 relative (observed against the oracle: tests/test_gpu_parity.py), strengths differ in
+    // second order only (the maximum is flat), voiced / unvoiced decisions are unchanged.
     unsigned int it = group;
     bool have = false;
     RefineItem item = {0, 0, 0};
@@ -986,6 +995,27 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
     bool fast = false;
     double yv[NR];
     double a = 0.0, b = 0.0, v = 0.0, w = 0.0, x = 0.0, fv = 0.0, fw = 0.0, fx = 0.0, t = 0.0;
+    const double tol_rel = P.refine_tol_rel;
+    // Brent's choice of the next trial point from the state (a, b, x, w, v); true: converged
+    auto next_point = [&]() -> bool {
+        const double range = b - a;
+        const double middle_range = (a + b) / 2.0;
+        const double tol_act = tol_rel * fabs(x) + tol / 3.0;
+        if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) return true;
+        double new_step = golden * (x < middle_range ? b - x : a - x);
+        if (fabs(x - w) >= tol_act) {
+            double tt = (x - w) * (fx - fv);
+            double q = (x - v) * (fx - fw);
+            double p = (x - v) * q - (x - w) * tt;
+            q = 2.0 * (q - tt);
+            if (q > 0.0) p = -p; else q = -q;
+            if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
+                new_step = p * rcp_f64(q);          // (an IEEE divide is ~35 instructions; this is within 1 ulp of it)
+        }
+        if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
+        t = x + new_step;
+        return false;
+    };
     for (;;) {
         while (!have && it < count) {
             item = items[it];
@@ -1008,8 +1038,17 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
                 yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[abs(ix - P.bix - 1)] : 0.0;
             }
             a = (double)(ixmid - 1); b = (double)(ixmid + 1);
-            v = a + golden * (b - a);
-            t = v; iter = 0; have = true;
+            iter = 0; have = true;
+            if (P.refine_seeded) {
+                // the interpolant passes through the samples: f(ixmid) = -r0, f(ixmid -+ 1) = -rm / -rp, for free
+                x = (double)ixmid; fx = -r0;
+                if (rm >= rp) { w = a; fw = -rm; v = b; fv = -rp; } else { w = b; fw = -rp; v = a; fv = -rm; }
+                iter = 1;
+                if (next_point()) { finish(item, x, -fx); have = false; }
+            } else {
+                v = a + golden * (b - a);                                    // Praat's own opening (PCE_PITCH_REFINE=praat: the iterates of NUMminimize_brent)
+                t = v;
+            }
         }
         if (__ballot(have) == 0) break;
         if (have) {
@@ -1026,28 +1065,7 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
                 else if (ft <= fv || v == x || v == w) { v = t; fv = ft; }
             }
             iter++;
-            bool done = iter > 60;
-            if (!done) {
-                const double range = b - a;
-                const double middle_range = (a + b) / 2.0;
-                const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.0;
-                if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) done = true;
-                else {
-                    double new_step = golden * (x < middle_range ? b - x : a - x);
-                    if (fabs(x - w) >= tol_act) {
-                        double tt = (x - w) * (fx - fv);
-                        double q = (x - v) * (fx - fw);
-                        double p = (x - v) * q - (x - w) * tt;
-                        q = 2.0 * (q - tt);
-                        if (q > 0.0) p = -p; else q = -q;
-                        if (fabs(p) < fabs(new_step * q) && p > q * (a - x + 2.0 * tol_act) && p < q * (b - x - 2.0 * tol_act))
-                            new_step = p * rcp_f64(q);          // (an IEEE divide is ~35 instructions; this is within 1 ulp of it)
-                    }
-                    if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
-                    t = x + new_step;
-                }
-            }
-            if (done) { finish(item, x, -fx); have = false; }
+            if (iter > 60 || next_point()) { finish(item, x, -fx); have = false; }
         }
     }
 }
@@ -1411,6 +1429,8 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             P.zlen = Mc + Mc / 8 + 2;
             P.rr_len = 2 * P.bix + 2;
             P.rr_half = (P.bix + 2) & ~1;                  // handoff row: r[0..bix], even length
+            P.refine_seeded = c->pitch_refine_praat ? 0 : 1;
+            P.refine_tol_rel = c->pitch_refine_praat ? 1.4901161193847656e-08 : 5e-8;
             const size_t lds_wave = sizeof(double) * 4 * (size_t)P.zlen;            // two complex buffers per wavefront
             if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
             // register-resident transforms where N allows it and r[-bix..bix] fits the exchange region
