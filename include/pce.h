@@ -306,6 +306,15 @@ int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_
                                int32_t *next_tokens /* [clips] */, float *next_logprobs /* [clips] or NULL */,
                                float *probe_prob /* [clips] or NULL */);
 
+/* Operand type of every Whisper / BERT matrix product (round 3).  PCE_OPERANDS_BF16 (default; PCE_WHISPER_OPERANDS=fp16 in the
+ * environment at pce_create selects the other): bf16 operands.  PCE_OPERANDS_FP16: fp16 operands, the reference's own arithmetic
+ * (openai-whisper runs in half precision: transcribe's fp16=True default behind Code/Aligners/use_whisper_timestamped.py:163).
+ * fp32 accumulation, fp32 LayerNorm / softmax statistics and an fp32 residual stream in both.  The two builds keep separate state:
+ * call this BEFORE pce_whisper_load / pce_whisper_decoder_load / pce_bert_load / pce_logmel_run, and load again after switching. */
+enum { PCE_OPERANDS_BF16 = 0, PCE_OPERANDS_FP16 = 1 };
+int pce_whisper_set_operands(pce_ctx *ctx, int32_t operand_type);
+int pce_whisper_get_operands(pce_ctx *ctx);
+
 /* The whole free-running loop on the device (round 3): what whisper.decoding.DecodingTask._main_loop does for a batch
  * (Code/Aligners/use_whisper_timestamped.py:150-163 -> whisper_timestamped.transcribe -> whisper.decode).  The prompts are uploaded
  * once; every later step takes the token it embeds, its position and the "ended" flags from device memory written by the previous

@@ -119,6 +119,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
     c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
     c->attn1 = !(getenv("PCE_ATTN1") && atoi(getenv("PCE_ATTN1")) == 0);
+    c->whisper_ops = (getenv("PCE_WHISPER_OPERANDS") && !strcmp(getenv("PCE_WHISPER_OPERANDS"), "fp16")) ? 1 : 0;
     c->attn_mode = getenv("PCE_ATTN") ? atoi(getenv("PCE_ATTN")) : 1;
     c->gemm_sm = getenv("PCE_GEMM_SM") ? atoi(getenv("PCE_GEMM_SM")) : 0;
     c->gemm_sn = getenv("PCE_GEMM_SN") ? atoi(getenv("PCE_GEMM_SN")) : 0;

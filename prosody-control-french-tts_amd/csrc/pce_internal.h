@@ -119,8 +119,10 @@ struct pce_ctx {
     std::vector<int64_t> py_off;
     bool py_ran = false;
 
-    // whisper (opaque: defined in pce_whisper.hip)
-    void *whisper = nullptr;
+    // whisper / BERT state, opaque (pce_whisper_impl.inc): one slot per operand-type build (0: bf16, 1: fp16); whisper_ops selects the build the
+    // entry points of include/pce.h forward to (pce_whisper_set_operands, or PCE_WHISPER_OPERANDS=fp16 at pce_create)
+    void *whisper_slot[2] = {nullptr, nullptr};
+    int whisper_ops = 0;
 
     // asynchronous statistics fetch (pce_stats_enqueue / pce_stats_wait)
     struct StatSlot {

@@ -83,8 +83,8 @@ struct PiParams {
     double dx, dt, min_pitch, ceiling, voicing_thr, octave_cost, silence_thr, oj_cost, vuv_cost;
     int nsp, hsp, nw, hw, maxlag, bix, maxc, nfft, zlen, rr_len, mode, fpb;
     int o_tw2, o_twN, o_win, o_winR, blob_f64, pcm_span, tabs, rr_half;   // register paths: table blob layout (offsets in doubles)
-    int refine_seeded, pad_;                                              // k_pitch_refine: 1 = Brent's state seeded with the three samples (default), 0 = Praat's own iterates
-    double refine_tol_rel;                                                // ... and the relative stopping tolerance (5e-8; Praat's own: sqrt(eps) = 1.49e-8)
+    int refine_seeded, pad_;                                              // k_pitch_refine: 1 = parabolic search first (default), 0 = Praat's own iterates for every candidate
+    double refine_tol_rel;                                                // ... and the relative step below which the parabolic search stops (3e-8)
 };
 struct PiSlice {
     int64_t begin, clip_len, clip_off, nx, frame_off;
@@ -975,32 +975,37 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
             cand[item.frame * 32 + 16 + item.slot] = yres;
         }
     };
-    // Brent's minimiser (Praat NUMimproveMaximum -> NUMminimize_brent on -sinc) as a state machine: every trip of the loop is ONE
-    // function evaluation for each of the wave's eight candidates, and a group whose candidate has converged fetches its next item
-    // at once, so candidates with different iteration counts do not wait for one another.
-    // Round 3: the search no longer replays Praat's iterates, it starts where they end up.  Praat opens with a golden-section point of
-    // [ixmid - 1, ixmid + 1] and needs 10-13 evaluations; here Brent's state is SEEDED with the three samples around the maximum
-    // (x = ixmid, w / v = its neighbours: their function values are the autocorrelation samples themselves, no evaluation), so the
-    // first trial point already is the parabolic estimate and the same safeguarded loop (parabolic step inside the bracket, else
-    // golden section; steps never shorter than the tolerance) closes in 4-6 evaluations.  Both searches end within the stopping
-    // tolerance of the one maximum of the interpolant in the bracket.  Tolerance: Praat stops at sqrt(eps) |x| + tol / 3 ~ 1.5e-8 |x|
-    // (x = 27-107 lags: ~1e-6 lags absolute, i.e. 1.5e-8 RELATIVE in F0); the parity gate is 1e-6 relative, so the stop here is
-    // 5e-8 |x| -- an F0 error of at most ~2e-7 relative (observed against the oracle: tests/test_gpu_parity.py), strengths differ in
-    // second order only (the maximum is flat), voiced / unvoiced decisions are unchanged.
+    // The maximiser as a state machine: every trip of the loop is ONE function evaluation for each of the wave's eight candidates, and a
+    // group whose candidate has converged fetches its next item at once, so candidates with different iteration counts do not wait for
+    // one another.  Two searches (round 3):
+    //   * successive parabolic interpolation seeded with the three samples around the maximum (their function values are the
+    //     autocorrelation samples themselves: no evaluation): the first trial point already is the parabolic estimate, and the fit through
+    //     the best three points converges superlinearly: 3-4 evaluations (stop: a step below 3e-8 |x| after a step below 1e-3).
+    //     Praat's NUMminimize_brent (a golden-section opening of [ixmid - 1, ixmid + 1], then a bracket that has to close to 1.5e-8 |x|
+    //     from both sides) takes 9-18 for the same maximum, whose position it reports within that tolerance: 1e-6 lags absolute, 1.5e-8
+    //     relative in F0, against a parity gate of 1e-6;
+    //   * Praat's own iterates, exactly as before, for the candidates where the two could differ by more than rounding: the
+    //     interpolant is smooth on either side of the sample ixmid but has a kink AT it (the sinc window changes with floor(x)), so a
+    //     maximum within a few thousandths of a lag of the sample can split into one local maximum per side (measured on synthetic
+    //     autocorrelations: discrepancies of 2e-5 .. 7e-5 relative, all within 0.007 lags of the sample) and which one the reference
+    //     reports depends on its path.  Every candidate whose parabolic search ends within 0.03 lags of the sample (3 %), or fails a
+    //     safeguard (step outside the bracket, no convergence in 10 steps), is searched again the reference's way.
+    // Elsewhere the maximum in the bracket is unique, both searches end within their tolerance of it, and the strengths agree to second
+    // order (the maximum is flat).  PCE_PITCH_REFINE=praat runs every candidate the reference's way.
     unsigned int it = group;
     bool have = false;
     RefineItem item = {0, 0, 0};
     const double *y = rr_in;
-    int wbase = 0, depth = 70, iter = 0;
+    int wbase = 0, depth = 70, iter = 0;             // iter >= 0: Brent's iteration count; iter < 0: parabolic search, -1 - evaluations so far
     bool fast = false;
     double yv[NR];
-    double a = 0.0, b = 0.0, v = 0.0, w = 0.0, x = 0.0, fv = 0.0, fw = 0.0, fx = 0.0, t = 0.0;
-    const double tol_rel = P.refine_tol_rel;
+    double a = 0.0, b = 0.0, v = 0.0, w = 0.0, x = 0.0, fv = 0.0, fw = 0.0, fx = 0.0, t = 0.0, prev_step = 1.0;
+    const double sqrt_epsilon = 1.4901161193847656e-08, spi_stop = P.refine_tol_rel;
     // Brent's choice of the next trial point from the state (a, b, x, w, v); true: converged
-    auto next_point = [&]() -> bool {
+    auto brent_next = [&]() -> bool {
         const double range = b - a;
         const double middle_range = (a + b) / 2.0;
-        const double tol_act = tol_rel * fabs(x) + tol / 3.0;
+        const double tol_act = sqrt_epsilon * fabs(x) + tol / 3.0;
         if (fabs(x - middle_range) + range / 2.0 <= 2.0 * tol_act) return true;
         double new_step = golden * (x < middle_range ? b - x : a - x);
         if (fabs(x - w) >= tol_act) {
@@ -1015,6 +1020,27 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
         if (fabs(new_step) < tol_act) new_step = new_step > 0.0 ? tol_act : -tol_act;
         t = x + new_step;
         return false;
+    };
+    auto brent_start = [&](double node) {
+        a = node - 1.0; b = node + 1.0;
+        v = a + golden * (b - a);
+        t = v; iter = 0;
+    };
+    // next point of the parabolic search: 0 = evaluate t, 1 = converged at x, 2 = leave it to Brent
+    auto spi_next = [&]() -> int {
+        const double tt = (x - w) * (fx - fv);
+        double q = (x - v) * (fx - fw);
+        double p = (x - v) * q - (x - w) * tt;
+        q = 2.0 * (q - tt);
+        if (q == 0.0) return 2;
+        if (q > 0.0) p = -p; else q = -q;
+        const double step = p * rcp_f64(q), tn = x + step;
+        if (!(tn > a && tn < b)) return 2;
+        const int n_eval = -1 - iter;
+        if (n_eval >= 2 && fabs(step) <= spi_stop * fabs(x) && fabs(prev_step) <= 1e-3) return 1;
+        if (n_eval >= 10) return 2;
+        prev_step = step; t = tn;
+        return 0;
     };
     for (;;) {
         while (!have && it < count) {
@@ -1037,18 +1063,15 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
                 const int ix = wbase + l8 + G * m;
                 yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[abs(ix - P.bix - 1)] : 0.0;
             }
-            a = (double)(ixmid - 1); b = (double)(ixmid + 1);
-            iter = 0; have = true;
+            have = true;
             if (P.refine_seeded) {
-                // the interpolant passes through the samples: f(ixmid) = -r0, f(ixmid -+ 1) = -rm / -rp, for free
+                // the interpolant passes through the samples: f(ixmid) = -r0, f(ixmid -+ 1) = -rm / -rp
+                a = (double)(ixmid - 1); b = (double)(ixmid + 1);
                 x = (double)ixmid; fx = -r0;
                 if (rm >= rp) { w = a; fw = -rm; v = b; fv = -rp; } else { w = b; fw = -rp; v = a; fv = -rm; }
-                iter = 1;
-                if (next_point()) { finish(item, x, -fx); have = false; }
-            } else {
-                v = a + golden * (b - a);                                    // Praat's own opening (PCE_PITCH_REFINE=praat: the iterates of NUMminimize_brent)
-                t = v;
-            }
+                iter = -1; prev_step = 1.0;
+                if (spi_next() != 0) brent_start((double)ixmid);
+            } else brent_start((double)ixmid);
         }
         if (__ballot(have) == 0) break;
         if (have) {
@@ -1064,8 +1087,16 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
                 if (ft <= fw || w == x) { v = w; w = t; fv = fw; fw = ft; }
                 else if (ft <= fv || v == x || v == w) { v = t; fv = ft; }
             }
-            iter++;
-            if (iter > 60 || next_point()) { finish(item, x, -fx); have = false; }
+            if (iter >= 0) {
+                iter++;
+                if (iter > 60 || brent_next()) { finish(item, x, -fx); have = false; }
+            } else {
+                iter--;
+                const double node = (double)(item.imax + P.bix + 1);
+                const int r = spi_next();
+                if (r == 1 && fabs(x - node) >= 0.03) { finish(item, x, -fx); have = false; }
+                else if (r != 0) brent_start(node);
+            }
         }
     }
 }
@@ -1430,7 +1461,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             P.rr_len = 2 * P.bix + 2;
             P.rr_half = (P.bix + 2) & ~1;                  // handoff row: r[0..bix], even length
             P.refine_seeded = c->pitch_refine_praat ? 0 : 1;
-            P.refine_tol_rel = c->pitch_refine_praat ? 1.4901161193847656e-08 : 5e-8;
+            P.refine_tol_rel = 3e-8;
             const size_t lds_wave = sizeof(double) * 4 * (size_t)P.zlen;            // two complex buffers per wavefront
             if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
             // register-resident transforms where N allows it and r[-bix..bix] fits the exchange region

@@ -109,7 +109,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop",
+           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_selftest_attention", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
@@ -159,6 +159,8 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_align_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_whisper_decode_step.argtypes = [vp, vp, vp, i32, C.POINTER(WhisperDecodeRules), vp, vp, vp]
     lib.pce_whisper_decode_step_ex.argtypes = [vp, vp, vp, C.POINTER(WhisperDecodeRules), vp, C.POINTER(WhisperDecodeOpts), vp, vp, vp]
+    lib.pce_whisper_set_operands.argtypes = [vp, i32]
+    lib.pce_whisper_get_operands.argtypes = [vp]
     lib.pce_whisper_decode_loop.argtypes = [vp, vp, vp, C.POINTER(WhisperDecodeRules), vp, C.POINTER(WhisperDecodeOpts), i32, i32, vp, vp, vp, vp]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
@@ -399,6 +401,21 @@ class ProsodyEngine:
         self._check(self._lib.pce_logmel_fetch(self._ctx, int(clip), out.ctypes.data))
         return out
 
+    # ---------------------------------------------------------------- operand type of the Whisper / BERT products
+    def whisper_set_operands(self, kind: str):
+        """``"bf16"`` (default) or ``"fp16"`` (the reference's own arithmetic: openai-whisper's fp16=True).  The two builds keep
+        separate state: select BEFORE loading weights / running the log-mel, and load again after switching."""
+        code = {"bf16": 0, "fp16": 1}[str(kind).lower()]
+        self._check(self._lib.pce_whisper_set_operands(self._ctx, code))
+
+    @property
+    def whisper_operands(self) -> str:
+        return "fp16" if self._lib.pce_whisper_get_operands(self._ctx) == 1 else "bf16"
+
+    def _op_dtype(self):
+        import torch
+        return torch.float16 if self.whisper_operands == "fp16" else torch.bfloat16
+
     def whisper_load(self, dims: dict, weights: np.ndarray):
         """``dims``: n_mels, n_ctx, n_state, n_head, n_layer; ``weights``: float32 blob in the order of include/pce.h."""
         w = np.ascontiguousarray(weights, dtype=np.float32)
@@ -417,12 +434,12 @@ class ProsodyEngine:
         float32 result decoded from bf16 ([M][N], or [clips][N][vt_sp] for the transposed epilogue 2).  ``epilogue`` >= 256 (a multiple of 256, < N)
         is the split launch: returns (row-major [M][epilogue], transposed image [clips][N - epilogue][vt_sp])."""
         import torch
-        a = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float32)).to(torch.bfloat16).contiguous()
-        b = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float32)).to(torch.bfloat16).contiguous()
+        a = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float32)).to(self._op_dtype()).contiguous()
+        b = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float32)).to(self._op_dtype()).contiguous()
         M, K = a.shape; N = b.shape[0]
         split = epilogue if epilogue >= 256 else 0
         n_out = (M // rows_per_clip) * N * vt_sp if epilogue == 2 else M * split + (M // rows_per_clip) * (N - split) * vt_sp if split else M * N
-        out = torch.zeros(n_out, dtype=torch.bfloat16)
+        out = torch.zeros(n_out, dtype=self._op_dtype())
         bv = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
         self._check(self._lib.pce_selftest_gemm(self._ctx, a.view(torch.int16).numpy().ctypes.data, b.view(torch.int16).numpy().ctypes.data,
                                                 bv.ctypes.data if bv is not None else None, M, N, K, int(epilogue), int(rows_per_clip), int(vt_sp),
@@ -437,7 +454,7 @@ class ProsodyEngine:
         arrays (rounded to bf16 here).  mode 0: as the engine runs it, 1: exact path only, 2: the round-1 kernel.  Returns (out float32 decoded
         from bf16, number of workgroups that fell back to the exact path)."""
         import torch
-        tq, tk, tv = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).contiguous() for x in (q, k, v))
+        tq, tk, tv = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._op_dtype()).contiguous() for x in (q, k, v))
         clips, q_len, hd = tq.shape
         k_len = tk.shape[1]
         assert hd % 64 == 0 and tk.shape == tv.shape == (clips, k_len, hd)

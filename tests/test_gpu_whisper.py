@@ -502,3 +502,72 @@ def test_attention_fixed_reference_overflow_takes_the_exact_path(engine):
         assert np.max(np.abs(got - want)) <= 2e-2, (boost, np.max(np.abs(got - want)))
         exact, _ = engine.selftest_attention(q, k2, v, False, 1)
         assert np.max(np.abs(exact - want)) <= 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp16 operands: the reference's own arithmetic (openai-whisper fp16=True), same kernels, same MFMA rate
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def fp16_engine(engine):
+    engine.whisper_set_operands("fp16")
+    assert engine.whisper_operands == "fp16"
+    yield engine
+    engine.whisper_set_operands("bf16")
+
+
+def test_fp16_operands_gemm_and_attention_units(fp16_engine):
+    """The persistent GEMM (plain, GELU, split Q|K|V launch) and both attention kernels on fp16 operands against torch fp32 on the
+    fp16-rounded operands: the error is the fp16 rounding of the OUTPUT (2^-11 relative: 8 x tighter than bf16's bounds above)."""
+    import torch
+    eng = fp16_engine
+    rng = np.random.default_rng(4)
+    M, N, K = 3000, 2304, 768
+    A = rng.standard_normal((M, K)).astype(np.float32); B = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    a = torch.from_numpy(A).to(torch.float16).float(); b = torch.from_numpy(B).to(torch.float16).float()
+    want = (a @ b.T + torch.from_numpy(bias)).numpy()
+    rm, vt = eng.selftest_gemm(A, B, bias, 1536, 1500, 1536)
+    got = np.concatenate([rm, np.concatenate([vt[c, :, :1500].T for c in range(M // 1500)])], axis=1)
+    err = np.abs(got - want)
+    assert np.linalg.norm(err) / np.linalg.norm(want) <= 6e-4 and (err <= np.abs(want) * 2.0 ** -10 + 2e-3).all()
+    got = eng.selftest_gemm(A, B[:1536], bias[:1536], 1)
+    wg = torch.nn.functional.gelu(torch.from_numpy(want[:, :1536])).numpy()
+    assert np.linalg.norm(got - wg) / np.linalg.norm(wg) <= 6e-4
+    q = rng.standard_normal((2, 200, 128)).astype(np.float32); k = rng.standard_normal((2, 333, 128)).astype(np.float32)
+    v = rng.standard_normal((2, 333, 128)).astype(np.float32)
+    f16 = lambda x: torch.from_numpy(x).to(torch.float16).float().numpy()
+    ref = _attention_reference(f16(q), f16(k), f16(v), False)
+    for mode in (0, 1, 2):
+        out, _ = eng.selftest_attention(q, k, v, causal=False, mode=mode)
+        assert np.max(np.abs(out - ref)) <= 3e-3, mode                 # P and the output are rounded to fp16 (bf16: 2e-2)
+
+
+def test_fp16_operands_full_depth_encoder_and_alignment(fp16_engine):
+    """Whisper-small at its 12 + 12 layers on fp16 operands against the float32 restatement: encoder output relative L2 <= 1.5e-3
+    (bf16 operands: 3.3e-3 observed, bound 2e-2), alignment cost <= 1e-2, the DTW path IS the recurrence's path on the engine's own
+    cost matrix, and the bf16 build still gives its own answer afterwards (separate state per operand type)."""
+    eng = fp16_engine
+    dims, tdims = WW.DIMS["small"], dict(WW.TEXT_DIMS["small"], n_vocab=2048)
+    W, Wd = WW.synthetic_weights(dims), WW.synthetic_decoder_weights(tdims)
+    clips2 = [synth.synth_clip(40 + i, seconds=10.0) for i in range(2)]
+    eng.upload(clips2, 16000)
+    eng.logmel_run(80)
+    eng.whisper_load(dims, WW.pack(W, dims))
+    eng.whisper_encode_run()
+    errs = []
+    for i in range(2):
+        got = eng.whisper_encode_fetch(i)
+        want = WO.encoder_forward(WO.log_mel(clips2[i], 80), W, dims)
+        errs.append(float(np.linalg.norm(got - want) / np.linalg.norm(want)))
+    print("fp16 encoder relative L2:", errs)
+    assert max(errs) <= 1.5e-3, errs
+    eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+    rng = np.random.default_rng(33)
+    toks = [rng.integers(0, tdims["n_vocab"], size=int(n)).tolist() for n in (24, 31)]
+    frames = [len(c) // 160 for c in clips2]
+    res = eng.whisper_align(toks, frames, 3, want_cost=True)
+    for i in range(2):
+        cost, ti, tj = WO.find_alignment(toks[i], eng.whisper_encode_fetch(i), Wd, tdims, frames[i], 3)
+        assert np.linalg.norm(res[i]["cost"] - cost) / np.linalg.norm(cost) <= 1e-2, i
+        wi, wj = WO.dtw_path(res[i]["cost"])
+        assert np.array_equal(res[i]["text_indices"], wi) and np.array_equal(res[i]["time_indices"], wj)
