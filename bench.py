@@ -201,6 +201,8 @@ def main():
                          "c2 (configs[1]): F0 + energy + LUFS + STFT only")
     ap.add_argument("--streamed-steps", type=int, default=4, help="extra steps with the batch uploaded from pinned host memory "
                     "(double buffered) for `streamed_value`; 0 = skip")
+    ap.add_argument("--transcribe-steps", type=int, default=32, help="c3: free-running decoding steps per window of the extra `transcribe` "
+                    "measurement (log-mel + encoder + device-resident decoding loop + forced alignment; never `value`); 0 = skip")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the rank launcher and the exchange (gloo, no engine, no throughput)")
     args = ap.parse_args()
@@ -388,6 +390,55 @@ def run_rank(args, world, rank, local_rank):
         except Exception as e:                                      # never lose the main line over the extra measurement
             streamed = {"error": repr(e)}
 
+    # What the reference's call actually runs per window (whisper_timestamped.transcribe, use_whisper_timestamped.py:150-163): log-mel +
+    # encoder + FREE-RUNNING decoding + forced alignment.  Extra measurement, never `value`: the decoding loop is device-resident
+    # (pce_whisper_decode_loop); end-of-text is suppressed so that every step is a live step for all clips (the worst case of a window).
+    transcribe = None
+    if wdims and args.transcribe_steps > 0:
+        try:
+            from prosody_control_french_tts_amd.Aligners import decoding as DEC
+            V = tdims["n_vocab"]
+            eot, ts_begin = 50257, 50364                             # the multilingual vocabulary layout
+            vm = DEC.vocab_mask(V, list(range(50258, 50363)) + [eot], [220, eot], 50363)
+            prompts = [[50258, 50265, 50359]] * args.clips            # <|startoftranscript|><|fr|><|transcribe|>
+            N = args.transcribe_steps
+
+            def window():
+                eng.logmel_run(wdims["n_mels"]); eng.whisper_encode_run(); eng.sync()
+                t0 = time.perf_counter()
+                toks, _, _ = eng.whisper_decode_loop(prompts, 3, eot, ts_begin, vm, N, 50)
+                t1 = time.perf_counter()
+                eng.whisper_align_run(align_tokens, align_frames, sot_len); eng.sync()
+                return t1 - t0, time.perf_counter() - t1, toks.shape[1]
+            window()
+            eng.profile_enable(True); eng.profile_reset()
+            fence(); tw0 = time.perf_counter()
+            reps = [window() for _ in range(2)]
+            fence(); tw = (time.perf_counter() - tw0) / len(reps)
+            pr = eng.profile(); eng.profile_enable(False)
+            loop_s = float(np.mean([r[0] for r in reps]))
+            d_, L_ = tdims["n_state"], tdims["n_layer"]
+            xkv_bytes = L_ * args.clips * (1500 * d_ * 2 + d_ * 1536 * 2)              # cross K rows + V^T image (key axis padded to 1536) of every layer
+            # the loop call = cross K / V projections (once per window) + the prompt's prefix step + N - 1 incremental steps
+            xproj_ms = pr.get("k_gemm_flat:xkv", {}).get("total_ms", 0.0) / len(reps)
+            step0_ms = pr.get("whisper_decode_step", {}).get("total_ms", 0.0) / len(reps)
+            inc_ms = (loop_s * 1e3 - step0_ms) / max(N - 1, 1)
+            transcribe = {"what": f"per window of {args.clips} clips: log-mel + encoder + device-resident free-running decoding ({N} steps, end-of-text "
+                                  "suppressed: every clip live at every step) + forced alignment; one upload and one download per window",
+                          "window_ms": tw * 1e3, "x_real_time": args.clips * args.seconds / tw, "decode_loop_ms": loop_s * 1e3,
+                          "first_step_ms_incl_cross_kv_projection": step0_ms, "cross_kv_projection_ms": xproj_ms,
+                          "ms_per_incremental_step": inc_ms, "steps": int(reps[0][2]), "alignment_ms_after_loop": float(np.mean([r[1] for r in reps])) * 1e3,
+                          "host_syncs_per_window": 2 + (N - 1) // 4,
+                          "roofline": {"bound": "hbm", "bytes_per_step": xkv_bytes, "achieved": xkv_bytes / (inc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": xkv_bytes / (inc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "note": "algorithmic bytes of an incremental step = the cross-attention K rows and V^T of all layers "
+                                               "(read once per step); weights (0.28 GB) and the self-attention cache are not counted"},
+                          "kernels": {k: {"ms_per_window": v["total_ms"] / len(reps), "launches_per_window": v["launches"] / len(reps)}
+                                      for k, v in pr.items() if k in ("k_cross_attn1", "k_gemm_skinny", "k_gemm_bf16", "k_attention_lean", "whisper_decode_loop",
+                                                                     "whisper_encoder", "whisper_align", "k_gemm_flat:xkv")}}
+        except Exception as e:                                      # never lose the main line over the extra measurement
+            transcribe = {"error": repr(e)}
+
     if rank == 0:
         # per-kernel figures (HIP events on the engine's stream around every launch)
         kernels = []
@@ -505,13 +556,13 @@ def run_rank(args, world, rank, local_rank):
                        else "audio-seconds/sec prosody throughput (no alignment leg), 16 kHz French"),
             "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (MFMA legs) + f64 (F0 / LUFS)" if wdims else "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": f"{eng.whisper_operands} (MFMA legs) + f64 (F0 / LUFS)" if wdims else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, " + what,
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)"},
             "roofline": roofline, "mfma_floor": floor, "gemm_shapes": gemm_shapes, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
-            "streamed_value": streamed, "device": info["name"], "host_cores": os.cpu_count(),
+            "streamed_value": streamed, "transcribe": transcribe, "device": info["name"], "host_cores": os.cpu_count(),
         }))
     eng.close()
     if world > 1:

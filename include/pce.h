@@ -387,7 +387,7 @@ enum pce_kernel_id {
      * ("k_gemm_flat:<shape>"; PCE_K_GEMM_FLAT keeps the launches no shape is named for) */
     PCE_K_ADD_LAYERNORM, PCE_K_STFT_RAW, PCE_K_LOGMEL_NORM, PCE_K_ATTENTION_LEAN,
     PCE_K_GEMM_FLAT_QKV, PCE_K_GEMM_FLAT_OUT, PCE_K_GEMM_FLAT_FC1, PCE_K_GEMM_FLAT_FC2, PCE_K_GEMM_FLAT_XKV,
-    PCE_K_DECODE_LOOP, PCE_K_CROSS_ATTN1, PCE_K_COUNT
+    PCE_K_DECODE_LOOP, PCE_K_CROSS_ATTN1, PCE_K_GEMM_SKINNY, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

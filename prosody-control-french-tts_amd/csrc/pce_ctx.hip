@@ -118,6 +118,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
     c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
+    c->gemm_skinny = !(getenv("PCE_GEMM_SKINNY") && atoi(getenv("PCE_GEMM_SKINNY")) == 0);
     c->attn1 = !(getenv("PCE_ATTN1") && atoi(getenv("PCE_ATTN1")) == 0);
     c->whisper_ops = (getenv("PCE_WHISPER_OPERANDS") && !strcmp(getenv("PCE_WHISPER_OPERANDS"), "fp16")) ? 1 : 0;
     c->attn_mode = getenv("PCE_ATTN") ? atoi(getenv("PCE_ATTN")) : 1;
@@ -352,7 +353,7 @@ const char *pce_kernel_name(int id)
         "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat",
         "k_add_layernorm", "k_stft_raw", "k_logmel_norm", "k_attention_lean",
         "k_gemm_flat:qkv", "k_gemm_flat:out", "k_gemm_flat:fc1", "k_gemm_flat:fc2", "k_gemm_flat:xkv",
-        "whisper_decode_loop", "k_cross_attn1"};
+        "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -99,7 +99,7 @@ KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs
               "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat",
               "k_add_layernorm", "k_stft_raw", "k_logmel_norm", "k_attention_lean",
               "k_gemm_flat:qkv", "k_gemm_flat:out", "k_gemm_flat:fc1", "k_gemm_flat:fc2", "k_gemm_flat:xkv",
-              "whisper_decode_loop", "k_cross_attn1"]     # = pce_kernel_name(id) for every id (tests/test_abi_and_shard.py)
+              "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny"]     # = pce_kernel_name(id) for every id (tests/test_abi_and_shard.py)
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
