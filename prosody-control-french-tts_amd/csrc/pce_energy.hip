@@ -15,11 +15,8 @@
 namespace {
 
 constexpr int EN_THREADS = 256;
-#ifndef PCE_EN_ITERS
-#define PCE_EN_ITERS 8
-#endif
-constexpr int EN_ITERS = PCE_EN_ITERS;
-constexpr int64_t EN_CHUNK = (int64_t)EN_THREADS * 8 * EN_ITERS;   // 16384 samples = 32 KiB
+// loads per lane in flight = chunk size / 4 KiB: 8 (32 KiB chunks) by default, 16 (64 KiB) with PCE_EN_ITERS=16 at pce_create
+static inline int64_t en_chunk(int iters) { return (int64_t)EN_THREADS * 8 * iters; }
 
 struct EnWork { int64_t g0, g1; int32_t slice; int32_t pad; };
 // m_hi = max(x + 32769) and m_lo = max(32768 - x) over the real samples (0 = no sample seen):
@@ -42,6 +39,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return v;
 }
 
+template <int EN_ITERS>
 __global__ __launch_bounds__(EN_THREADS) void k_energy(const int16_t *__restrict__ pcm, const EnWork *__restrict__ work,
                                                       int loud_thr, EnAcc *__restrict__ out)
 {
@@ -151,6 +149,7 @@ int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work
         int64_t b = s.begin < 0 ? 0 : s.begin, e = s.end > len ? len : s.end;
         if (e <= b) continue;
         const int64_t g0 = c->clip_off[s.clip] + b, g1 = c->clip_off[s.clip] + e;
+        const int64_t EN_CHUNK = en_chunk(c->en_iters);
         for (int64_t p = g0; p < g1;) {
             int64_t q = ((p / EN_CHUNK) + 1) * EN_CHUNK;
             if (q > g1) q = g1;
@@ -174,8 +173,10 @@ int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, D
     PCE_HIP(c, hipMemsetAsync(out_buf.p, 0, sizeof(EnAcc) * (size_t)(n > 0 ? n : 1), st));
     if (n_work > 0) {
         KernelTimer t(c, PCE_K_ENERGY, st);
-        hipLaunchKernelGGL(k_energy, dim3((unsigned)n_work), dim3(EN_THREADS), 0, st,
-                           c->d_pcm, work_buf.as<EnWork>(), (int)loud_thr, out_buf.as<EnAcc>());
+        if (c->en_iters == 16)
+            hipLaunchKernelGGL(k_energy<16>, dim3((unsigned)n_work), dim3(EN_THREADS), 0, st, c->d_pcm, work_buf.as<EnWork>(), (int)loud_thr, out_buf.as<EnAcc>());
+        else
+            hipLaunchKernelGGL(k_energy<8>, dim3((unsigned)n_work), dim3(EN_THREADS), 0, st, c->d_pcm, work_buf.as<EnWork>(), (int)loud_thr, out_buf.as<EnAcc>());
         PCE_HIP(c, hipGetLastError());
     }
     return PCE_OK;

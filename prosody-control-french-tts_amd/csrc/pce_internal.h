@@ -73,6 +73,7 @@ struct pce_ctx {
     int32_t rate = 0;
 
     // energy
+    int en_iters = 8;               // PCE_EN_ITERS at pce_create (8 or 16): 16-byte loads per lane in flight = chunk size / 4 KiB
     DevBuf en_work, en_out;
     SliceCache en_cache;
     int64_t en_n_work = 0;

@@ -21,6 +21,27 @@ def engine():
     eng.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_operands(request):
+    """GPU tests start on the default operand type (fp16) whatever the previous test selected."""
+    if "engine" in request.fixturenames:
+        request.getfixturevalue("engine").whisper_set_operands("fp16")
+    yield
+
+
+# what the rounding of a 16-bit OUTPUT allows per operand type: unit-test bounds of the GEMM / attention kernels
+OPERANDS = {"bf16": dict(torch="bfloat16", l2=4e-3, rel=2.0 ** -7, abs=1e-2, attn_abs=1e-2, attn_l2=6e-3),
+            "fp16": dict(torch="float16", l2=6e-4, rel=2.0 ** -10, abs=2e-3, attn_abs=2e-3, attn_l2=1e-3)}
+
+
+@pytest.fixture(params=["fp16", "bf16"])
+def ops(request, engine):
+    """Runs a test once per operand type of the Whisper / BERT kernels; yields that type's name, torch dtype name and bounds."""
+    engine.whisper_set_operands(request.param)
+    yield dict(OPERANDS[request.param], name=request.param)
+    engine.whisper_set_operands("fp16")
+
+
 @pytest.fixture(scope="session")
 def synth16k():
     """Four deterministic 3-second 16 kHz clips + edge cases used by several parity tests."""
