@@ -423,6 +423,66 @@ class AudioPipeline:
             txt.rename(self.results_dir / txt.name)
         logging.info(f"Final transcription files saved in {self.results_dir}")
 
+    # ------------------------------------------------------------------ break prediction (BASELINE.json configs[4]: additive, not a reference step)
+    def predict_breaks(self, word_piecer=None, weights=None, dims=None, cls_id: int = 101, sep_id: int = 102):
+        """Break prediction for every segment of the voice with the token classifier the reference trains
+        (Code/baseline_models/pause_bert.py:14-21,127-132; the reference has no inference step: this is the forward a pipeline would
+        call).  One sentence per segment = the words of its cleaned transcription (``<voice>/transcription/<segment>.txt``).
+
+        ``word_piecer(word) -> [sub-token ids]``: the checkpoint's WordPiece split (``transformers.BertTokenizer(vocab_file)`` offline;
+        additive config key ``break_bert_vocab``); ``weights`` / ``dims``: a ``BertForTokenClassification`` state dict and its dims
+        (additive key ``break_bert_weights``: ``.npz`` / ``.safetensors``), loaded into the engine once.
+
+        Sharding: sentences are independent, so under an initialised ``torch.distributed`` rank r classifies a contiguous block of the
+        segment-sorted list and ONE all-gather of the 0 / 1 labels (padded to the longest sentence) gives every rank the whole table;
+        rank 0 writes ``results/<voice>/BDD_breaks.csv`` (segment, word_index, word, break)."""
+        from . import bert_weights as BW, shard
+        from .Preprocessing import break_bert as BB
+        eng = self._get_engine()
+        if weights is None and self.cfg.get("break_bert_weights"):
+            path = str(self.cfg["break_bert_weights"])
+            if path.endswith(".npz"):
+                with np.load(path) as z:
+                    weights = {k: z[k] for k in z.files}
+            else:
+                from safetensors.numpy import load_file
+                weights = load_file(path)
+        if weights is not None:
+            if dims is None:
+                d = weights["bert.embeddings.word_embeddings.weight"].shape
+                n_layer = 1 + max(int(k.split(".")[3]) for k in weights if k.startswith("bert.encoder.layer."))
+                dims = dict(n_vocab=int(d[0]), n_pos=int(weights["bert.embeddings.position_embeddings.weight"].shape[0]),
+                            n_type=int(weights["bert.embeddings.token_type_embeddings.weight"].shape[0]), n_state=int(d[1]), n_head=int(d[1]) // 64,
+                            n_layer=n_layer, n_labels=int(weights["classifier.weight"].shape[0]))
+            eng.bert_load(dims, BW.pack(weights, dims))
+        if word_piecer is None:
+            vocab = self.cfg.get("break_bert_vocab")
+            if not vocab:
+                raise FileNotFoundError('break prediction needs the checkpoint\'s WordPiece vocabulary: set "break_bert_vocab" (vocab.txt) or pass word_piecer')
+            from transformers import BertTokenizer
+            tok = BertTokenizer(str(vocab), do_lower_case=True)
+            cls_id, sep_id = tok.cls_token_id, tok.sep_token_id
+            word_piecer = lambda w: tok.convert_tokens_to_ids(tok.tokenize(w))
+        txts = sorted(self.transcription_dir.glob("*.txt"), key=lambda p: segment_sort_key(p.stem))
+        words = [t.read_text(encoding="utf-8").split() for t in txts]
+        rank, world = shard.rank_world()
+        lo, hi = shard.shard_range(len(txts), rank, world)
+        mine = [[word_piecer(w) for w in ws] for ws in words[lo:hi]]
+        local = BB.predict_breaks(eng, mine, cls_id, sep_id) if mine else []
+        width = max([len(ws) for ws in words] + [1])
+        rec = np.full((len(local), width), -1.0)
+        for i, lab in enumerate(local):
+            rec[i, :len(lab)] = lab
+        counts = [b - a for a, b in (shard.shard_range(len(txts), r, world) for r in range(world))]
+        allrec = shard.allgather_records(rec, counts)
+        labels = [[int(v) for v in allrec[i, :len(ws)]] for i, ws in enumerate(words)]
+        if rank == 0:
+            import pandas as pd
+            rows = [{"segment": t.stem, "word_index": k, "word": w, "break": b} for t, ws, lab in zip(txts, words, labels) for k, (w, b) in enumerate(zip(ws, lab))]
+            pd.DataFrame(rows, columns=["segment", "word_index", "word", "break"]).to_csv(self.results_dir / "BDD_breaks.csv", index=False)
+        shard.barrier()
+        return dict(zip([t.stem for t in txts], labels))
+
     # ------------------------------------------------------------------ step table
     def run(self):
         """Code/audioPipeline.py:1076-1103: the selected steps in the fixed order, ``sys.exit(1)`` when one raises, then
@@ -444,3 +504,84 @@ class AudioPipeline:
         with open(config_path, "w", encoding="utf-8") as f:
             yaml.dump(self.cfg, f, default_flow_style=False, allow_unicode=True)
         logging.info(f"Config saved to {config_path}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the driver of Code/audioPipeline.py:1105-1160, mapped onto one process per GPU
+# ---------------------------------------------------------------------------------------------------------------
+def run_pipeline_for_voice(args):
+    """``run_pipeline_for_voice((name, cfg))`` of the reference (:1105-1119): (success, name)."""
+    name, cfg = args
+    base = cfg.get("_base")
+    logging.info(f"--- Starting pipeline for: {name} ---")
+    try:
+        AudioPipeline(name, {k: v for k, v in cfg.items() if k != "_base"}, base=base).run()
+        logging.info(f"--- Finished pipeline for: {name} ---")
+        return True, name
+    except SystemExit as e:                                                  # run() exits on a failed step, as the reference does
+        logging.error(f"--- Pipeline failed for: {name} --- (exit {e.code})")
+        return False, name
+    except Exception as e:                                                   # noqa: BLE001
+        logging.error(f"--- Pipeline failed for: {name} ---")
+        logging.exception(e)
+        return False, name
+
+
+def run_all(cfg, base=None):
+    """The ``__main__`` block of the reference (:1121-1160).  The reference parallelises over VOICES with a ``spawn`` pool of
+    ``num_processes`` workers, each owning a Whisper model on the one GPU (config.yaml:58).  Here the unit of parallelism is the
+    GPU: launched as one process per GPU (``python -m torch.distributed.run --nproc-per-node 8 ... -m prosody_control_french_tts_amd.audio_pipeline
+    config.yaml``), every voice is processed by ALL ranks together -- each step shards the voice's utterances over the ranks
+    (``measure_prosody_and_build_ssml``: one all-gather; the aligner: none; ``predict_breaks``: one all-gather) -- and the voices
+    follow one another.  ``multiprocessing`` / ``num_processes`` are accepted and ignored under a process group; without one this is
+    the reference's sequential loop on one GPU.  -> the list of voices that failed."""
+    from . import shard
+    names = cfg.get("voice_names")
+    if not names:
+        logging.error("Missing 'voice_names' in config.yaml")
+        sys.exit(1)
+    if isinstance(names, str):
+        names = [names]
+    elif not isinstance(names, list):
+        logging.error("'voice_names' in config.yaml must be a string or a list")
+        sys.exit(1)
+    rank, world = shard.rank_world()
+    logging.info(f"Processing voices: {', '.join(names)}" + (f" (rank {rank} of {world}: utterances of every voice sharded over the ranks)" if world > 1 else ""))
+    if cfg.get("multiprocessing") and world > 1:
+        logging.info("multiprocessing / num_processes ignored: parallelism comes from the one-process-per-GPU launch")
+    failed = []
+    for name in names:
+        ok, _ = run_pipeline_for_voice((name, dict(cfg, _base=base)))
+        if not ok:
+            failed.append(name)
+    if failed:
+        logging.error(f"Some pipelines failed: {', '.join(failed)}")
+    return failed
+
+
+def main(argv=None):
+    """``python -m prosody_control_french_tts_amd.audio_pipeline [config.yaml]``; initialises torch.distributed (RCCL) when started by
+    a launcher that sets WORLD_SIZE > 1."""
+    import os
+    import yaml
+    argv = sys.argv[1:] if argv is None else argv
+    path = Path(argv[0]) if argv else Path("config.yaml")
+    with open(path, encoding="utf-8") as f:
+        cfg = yaml.safe_load(f)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    failed = run_all(cfg, base=path.resolve().parent)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -228,6 +228,29 @@ assert len(calls) == 1, calls                                  # ONE collective
 n_up = OracleEngine.uploaded
 assert n_up == 2 * (3 if rank == 0 else 2), n_up               # only this rank's block was decoded and uploaded (nat + syn files)
 sharded = {p.name: p.read_text(encoding="utf-8") for p in (ap.bdd_ssml_csv, ap.bdd_syntagme_ssml_csv, ap.bdd_syntagme_synth_csv)}
+# break prediction (configs[4]): sentences sharded over the ranks, ONE more all-gather, every rank gets every label
+if rank == 0:
+    (voice / "transcription").mkdir(exist_ok=True)
+    for k in range(5):
+        (voice / "transcription" / f"segment_ph{k + 1}.txt").write_text(" ".join(["mot"] * (3 + k)) + " fin", encoding="utf-8")
+dist.barrier()
+class BertStub(OracleEngine):
+    seen = 0
+    def bert_run(self, token_lists):
+        self.toks = [list(t) for t in token_lists]; BertStub.seen += len(token_lists)
+    def bert_fetch(self, i):
+        t = np.asarray(self.toks[i]); lab = (t % 2).astype(np.int32)           # "break after odd ids"
+        return np.zeros((len(t), 2), np.float32), lab
+apb = AudioPipeline("v1", cfg, base=base, engine=BertStub())
+piece = lambda w: [7 + len(w)] if w == "mot" else [12, 13]
+got = apb.predict_breaks(word_piecer=piece, cls_id=1, sep_id=2)
+assert len(calls) == 2 and BertStub.seen == (3 if rank == 0 else 2), (calls, BertStub.seen)
+assert got == {f"segment_ph{k + 1}": [0] * (3 + k) + [0] for k in range(5)}, got      # "mot" -> id 10 (even), "fin" -> first piece 12 (even)
+piece2 = lambda w: [11] if w == "mot" else [12, 13]
+assert apb.predict_breaks(word_piecer=piece2, cls_id=1, sep_id=2)["segment_ph3"] == [1] * 5 + [0]
+dist.barrier()
+if rank == 0:
+    assert (apb.results_dir / "BDD_breaks.csv").read_text(encoding="utf-8").splitlines()[0] == "segment,word_index,word,break"
 assert len(res.bdd_syntagme_ssml) == len(res.rows) > 5
 dist.barrier(); dist.destroy_process_group()
 # the same step without a process group (single rank, unsharded path) writes the same three files, text for text

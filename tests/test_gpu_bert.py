@@ -80,3 +80,26 @@ def test_predict_breaks_reads_the_first_subtoken(engine):
                 assert g[w] == 0
             elif abs(want[p, 1] - want[p, 0]) > 0.15:
                 assert g[w] == int(np.argmax(want[p]))
+
+
+def test_audio_pipeline_predict_breaks_on_the_engine(engine, tmp_path):
+    """BASELINE.json configs[4]'s break-prediction forward reached from ``AudioPipeline`` (world size 1 here; the sharding over ranks
+    and its one all-gather run under gloo in tests/test_abi_and_shard.py): one sentence per segment from the voice's cleaned
+    transcriptions, labels = the first sub-token's arg-max per word, the table written as BDD_breaks.csv."""
+    from prosody_control_french_tts_amd.audio_pipeline import AudioPipeline
+    from prosody_control_french_tts_amd.Preprocessing import break_bert as BB
+    dims = BW.DIMS["tiny"]
+    W = BW.synthetic_weights(dims, seed=5)
+    cfg = {"data_dir": "Data", "out_dir": "Out", "whisper_device": "cuda:0", "steps_to_run": []}
+    ap = AudioPipeline("v1", cfg, base=tmp_path, engine=engine)
+    ap.transcription_dir.mkdir(parents=True)
+    texts = {"segment_ph1": "bonjour tout le monde", "segment_ph2": "oui", "segment_ph10": "une phrase nettement plus longue que les autres ici"}
+    for k, t in texts.items():
+        (ap.transcription_dir / f"{k}.txt").write_text(t, encoding="utf-8")
+    piece = lambda w: [3 + (sum(map(ord, w)) % 250), 5 + len(w)][: 1 + len(w) % 2]
+    got = ap.predict_breaks(word_piecer=piece, weights=W, dims=dims, cls_id=1, sep_id=2)
+    assert list(got) == ["segment_ph1", "segment_ph2", "segment_ph10"]                      # segment order, as every table of the pipeline
+    want = BB.predict_breaks(engine, [[piece(w) for w in texts[k].split()] for k in got], 1, 2)
+    assert [got[k] for k in got] == want and all(len(got[k]) == len(texts[k].split()) for k in got)
+    rows = (ap.results_dir / "BDD_breaks.csv").read_text(encoding="utf-8").splitlines()
+    assert rows[0] == "segment,word_index,word,break" and len(rows) == 1 + sum(len(t.split()) for t in texts.values())
