@@ -411,11 +411,14 @@ def run_rank(args, world, rank, local_rank):
                 eng.whisper_align_run(align_tokens, align_frames, sot_len); eng.sync()
                 return t1 - t0, time.perf_counter() - t1, toks.shape[1]
             window()
-            eng.profile_enable(True); eng.profile_reset()
+            eng.profile_enable(False)                                 # the timed windows carry no per-kernel event pairs (70 of them per step cost 0.6 ms of one)
             fence(); tw0 = time.perf_counter()
             reps = [window() for _ in range(2)]
             fence(); tw = (time.perf_counter() - tw0) / len(reps)
+            eng.profile_enable(True); eng.profile_reset()
+            window()                                                  # one more window for the per-kernel split
             pr = eng.profile(); eng.profile_enable(False)
+            pr = {k: dict(v, total_ms=v["total_ms"] * len(reps), launches=v["launches"] * len(reps)) for k, v in pr.items()}
             loop_s = float(np.mean([r[0] for r in reps]))
             d_, L_ = tdims["n_state"], tdims["n_layer"]
             xkv_bytes = L_ * args.clips * (1500 * d_ * 2 + d_ * 1536 * 2)              # cross K rows + V^T image (key axis padded to 1536) of every layer
