@@ -60,6 +60,7 @@ struct pce_ctx {
     int attn_mode = 1;                   // PCE_ATTN at pce_create: 1 = k_attention_lean (default), 2 = its exact path only, 0 = k_attention (round 1)
     int gemm_sm = 0, gemm_sn = 0, gemm_wide = -1; bool gemm_trace = false;   // PCE_GEMM_SM / _SN / _WIDE / _TRACE: rasterisation and tile-shape overrides, phase stamps (tiled kernels)
     bool gemm_flat_attr[4] = {false, false, false, false};   // k_gemm_flat<EPI>: dynamic-LDS opt-in done on this context's device
+    bool gemm_few_rows = false;          // set by the incremental decoding step around its launches: k_gemm_skinny is eligible
     bool gemm_skinny = true, gemm_skinny_attr[4] = {false, false, false, false};   // PCE_GEMM_SKINNY=0 at pce_create: few-row launches stay on the 128 x 128 kernel
     bool gemm_flat = true;               // PCE_GEMM_FLAT=0 at pce_create: the encoder's projections stay on the 128 x 128 / 128 x 256 tile kernels
     bool stft_two_fft = false;           // PCE_STFT_TWO_FFT at pce_create: traffic-minimal STFT-dB (the FFT runs twice)

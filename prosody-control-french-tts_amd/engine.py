@@ -437,6 +437,14 @@ class ProsodyEngine:
         a = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float32)).to(self._op_dtype()).contiguous()
         b = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float32)).to(self._op_dtype()).contiguous()
         M, K = a.shape; N = b.shape[0]
+        if 16 <= epilogue <= 19:                                    # the tiled / few-row kernels behind launch_gemm (see pce_selftest_gemm)
+            f32 = epilogue == 19
+            outb = np.zeros(M * N, dtype=np.float32) if f32 else torch.zeros(M * N, dtype=self._op_dtype())
+            bvv = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+            self._check(self._lib.pce_selftest_gemm(self._ctx, a.view(torch.int16).numpy().ctypes.data, b.view(torch.int16).numpy().ctypes.data,
+                                                    bvv.ctypes.data if bvv is not None else None, M, N, K, int(epilogue), 1, 0,
+                                                    outb.ctypes.data if f32 else outb.view(torch.int16).numpy().ctypes.data))
+            return outb.reshape(M, N) if f32 else outb.float().numpy().reshape(M, N)
         split = epilogue if epilogue >= 256 else 0
         n_out = (M // rows_per_clip) * N * vt_sp if epilogue == 2 else M * split + (M // rows_per_clip) * (N - split) * vt_sp if split else M * N
         out = torch.zeros(n_out, dtype=self._op_dtype())

@@ -25,7 +25,7 @@ def engine():
 def _default_operands(request):
     """GPU tests start on the default operand type (fp16) whatever the previous test selected."""
     if "engine" in request.fixturenames:
-        request.getfixturevalue("engine").whisper_set_operands("fp16")
+        request.getfixturevalue("engine").whisper_set_operands(os.environ.get("PCE_TEST_OPERANDS", "fp16"))
     yield
 
 

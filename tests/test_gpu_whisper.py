@@ -445,6 +445,28 @@ def test_persistent_256_gemm_split_launch(engine, ops, shape):
     assert (err <= np.abs(want) * ops["rel"] + ops["abs"]).all()
 
 
+@pytest.mark.parametrize("shape", [(256, 768, 768), (256, 3072, 768), (256, 768, 3072), (200, 2304, 768), (3, 768, 768)])
+def test_few_row_gemm_against_torch(engine, ops, shape):
+    """k_gemm_skinny (the projections of an incremental decoding step: M = sequences, one row each) through the self-test entry point:
+    bias, bias + GELU (16-bit outputs) and accumulate-into-fp32 epilogues against torch fp32 on the rounded operands, at the shapes of a
+    Whisper-small decoder layer, a ragged row count and a three-sequence batch."""
+    import torch
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32); B = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dt = getattr(torch, ops["torch"])
+    a = torch.from_numpy(A).to(dt).float(); b = torch.from_numpy(B).to(dt).float()
+    want = a @ b.T + torch.from_numpy(bias)
+    for epi, ref in ((16, want), (17, torch.nn.functional.gelu(want)), (19, want)):
+        got = engine.selftest_gemm(A, B, bias, epi)
+        err = np.abs(got - ref.numpy())
+        if epi == 19:
+            assert np.max(err) <= 2e-4                                   # fp32 out: only the summation order differs from torch
+        else:
+            assert np.linalg.norm(err) / np.linalg.norm(ref.numpy()) <= ops["l2"] and (err <= np.abs(ref.numpy()) * ops["rel"] + ops["abs"]).all()
+
+
 def test_persistent_256_gemm_is_deterministic_and_row_count_independent(engine):
     """Each output element is one lane's fixed-order sum: a row block gives the same BITS whether 6 000 or 96 000 rows are in
     the product (other tile order, other workgroup, other ring phase), run after run.  (Two scheduling bugs showed up as
