@@ -54,7 +54,7 @@ struct pce_ctx {
     // debugging / tuning knobs, read once at pce_create (never in a launch path)
     bool pitch_refine_praat = false;     // PCE_PITCH_REFINE=praat at pce_create: the candidate refinement replays NUMminimize_brent's own iterates (round 1 / 2 behaviour)
     bool dbg_pitch_lds_fft = false; int dbg_pitch_tabs = -1, dbg_pitch = 0, refine_blocks_per_cu = 24;
-    int attn1 = 1;                       // PCE_ATTN1 at pce_create: 0 = incremental decoding steps keep the MFMA attention kernel (one live query per tile), 1 = k_cross_attn1
+    int attn1 = 2;                       // PCE_ATTN1 at pce_create (default 2): 0 = incremental decoding steps keep the MFMA attention kernel (one live query per tile), 1 = k_cross_attn1
                                          // (a workgroup per clip and head), 2 = k_cross_attn1w (a workgroup per clip, a wave per head)
     bool attn1w_attr = false;
     int attn_mode = 1;                   // PCE_ATTN at pce_create: 1 = k_attention_lean (default), 2 = its exact path only, 0 = k_attention (round 1)
