@@ -1042,10 +1042,15 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
         prev_step = step; t = tn;
         return 0;
     };
+    // a group's next item is fetched one item ahead and the 21 autocorrelation values of an item are requested together: one memory
+    // round trip per item stands in the wave's instruction stream, not three
+    RefineItem nxt = {0, 0, 0};
+    if (it < count) nxt = items[it];
     for (;;) {
         while (!have && it < count) {
-            item = items[it];
+            item = nxt;
             it += n_groups;
+            if (it < count) nxt = items[it];
             y = rr_in + item.frame * (long long)P.rr_half;               // Praat's y(i) = r[i - mid] = y[|i - mid|], mid = bix + 1
             const int ixmid = item.imax + P.bix + 1;
             if (ixmid <= 1) { finish(item, 1.0, y[P.bix]); continue; }
@@ -1059,9 +1064,9 @@ __global__ __launch_bounds__(256, G == 8 ? 3 : 2) void k_pitch_refine(PiParams P
             fast = depth == 70 && ixmid - 1 >= 9 && ynx - ixmid >= 8;
             wbase = ixmid - 71;
 #pragma unroll
-            for (int m = 0; m < NR; m++) {
+            for (int m = 0; m < NR; m++) {                                 // (loaded whether or not the fast path will use them)
                 const int ix = wbase + l8 + G * m;
-                yv[m] = (fast && ix >= 1 && ix <= ynx) ? y[abs(ix - P.bix - 1)] : 0.0;
+                yv[m] = (ix >= 1 && ix <= ynx) ? y[abs(ix - P.bix - 1)] : 0.0;
             }
             have = true;
             if (P.refine_seeded) {
@@ -1616,10 +1621,16 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             }
             {
                 KernelTimer t(c, PCE_K_PITCH_REFINE);
-                // 3 workgroups per CU are resident (168 VGPRs); 24 per CU measured best (1.30 ms against 1.47 at 3: the lists are uneven)
-                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (unsigned)c->refine_blocks_per_cu;
-                hipLaunchKernelGGL(k_pitch_refine<8>, dim3(blocks), dim3(256), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
-                                   list_cap, c->pi_cand.as<double>());   // (4 lanes per candidate measured slower: 1.66 against 1.35 ms)
+                // 12 wavefronts per CU are resident (168 VGPRs); 96 per CU measured best (the lists and the iteration counts are uneven), as
+                // ONE-wavefront workgroups: a slot is free again when its wavefront ends, not when the slowest of four does (0.98 -> 0.89-0.93 ms).
+                // Tried and dropped in round 3: 4 or 16 lanes per candidate (1.66 / 1.02 ms against 0.98); the refinement inside
+                // k_pitch_frames, on the autocorrelation still in LDS (no hand-off through HBM: -700 MB per C2 step): 3.07 ms for the
+                // fused kernel against 0.95 + 0.98 -- a wavefront's two frames hold ~11 candidates, so its eight lane groups run two rounds of
+                // 3-4 dependent evaluations at 70 % occupancy of the lanes, serialised behind its own transforms, where this kernel packs
+                // eight candidates of any frames into every wavefront.
+                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (unsigned)c->refine_blocks_per_cu * 4u;
+                hipLaunchKernelGGL(k_pitch_refine<8>, dim3(blocks), dim3(64), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
+                                   list_cap, c->pi_cand.as<double>());
             }
         }
         {
