@@ -118,6 +118,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->stft_two_fft = getenv("PCE_STFT_TWO_FFT") != nullptr;
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
     c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
+    c->en_cpb = getenv("PCE_EN_CPB") ? atoi(getenv("PCE_EN_CPB")) : 0;
     c->en_iters = (getenv("PCE_EN_ITERS") && atoi(getenv("PCE_EN_ITERS")) == 16) ? 16 : 8;
     c->gemm_skinny = !(getenv("PCE_GEMM_SKINNY") && atoi(getenv("PCE_GEMM_SKINNY")) == 0);
     c->attn1 = getenv("PCE_ATTN1") ? atoi(getenv("PCE_ATTN1")) : 2;    // measured: 115.8 (wave per head) vs 119.6 us (workgroup per head) per launch

@@ -76,6 +76,7 @@ struct pce_ctx {
     int32_t rate = 0;
 
     // energy
+    int en_cpb = 0;                 // PCE_EN_CPB: chunks per k_energy workgroup (0 = by batch size)
     int en_iters = 8;               // PCE_EN_ITERS at pce_create (8 or 16): 16-byte loads per lane in flight = chunk size / 4 KiB
     DevBuf en_work, en_out;
     SliceCache en_cache;
