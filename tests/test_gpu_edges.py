@@ -195,6 +195,34 @@ def test_side_streams_do_not_change_results(engine, synth16k, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cpb", ["1", "3", "8"])
+def test_energy_chunks_per_workgroup_do_not_change_results(monkeypatch, cpb):
+    """k_energy streams `cpb` consecutive 32 KB chunks per workgroup and adds to a slice's accumulators once per (workgroup, slice):
+    forced to 1 / 3 / 8 chunks on a batch whose slices start and end anywhere (several slices inside one chunk, slices that span
+    many chunks, unaligned ends, empty and out-of-clip ranges) the seven integer statistics equal the numpy restatement exactly."""
+    rng = np.random.default_rng(123)
+    clips = [rng.integers(-32768, 32768, size=n).astype(np.int16) for n in (200001, 16384 * 3, 5, 70000, 16383, 16385)]
+    idx, b, e = [], [], []
+    for ci, c in enumerate(clips):
+        n = len(c)
+        idx += [ci] * 6
+        b += [0, 1, n // 3, max(n - 9, 0), -50, n // 2]
+        e += [n, min(n, 17), n // 3 + 40000, n, 10, n // 2]
+    sl = E.make_slices(idx, b, e)
+    monkeypatch.setenv("PCE_EN_CPB", cpb)
+    with pkg.ProsodyEngine(0) as eng:
+        eng.upload(clips, 16000)
+        got = eng.energy(sl, 500)
+    for k, (ci, b0, e0) in enumerate(zip(idx, b, e)):
+        x = clips[ci][max(b0, 0):max(min(e0, len(clips[ci])), 0)].astype(np.int64)
+        assert got["n"][k] == e0 - b0
+        assert got["sum_sq"][k] == int(np.sum(x * x)), (cpb, k)
+        assert got["sum_sq_wrap16"][k] == int(np.sum((x * x).astype(np.int16).astype(np.int64))), (cpb, k)
+        assert got["n_loud"][k] == int(np.sum(np.abs(x.astype(np.int16)) > 500)), (cpb, k)
+        assert got["peak_abs"][k] == (int(np.max(np.abs(x))) if len(x) else 0), (cpb, k)
+
+
+@pytest.mark.gpu
 def test_stft_one_fft_and_two_fft_forms_agree_bitwise(engine, synth16k, monkeypatch):
     """Default: one FFT pass writing unnormalised dB + an in-place normalisation pass on a side stream.
     PCE_STFT_TWO_FFT=1: maximum pass, then the dB pass (each byte moved once).  Same float operations in the
