@@ -530,7 +530,7 @@ def run_rank(args, world, rank, local_rank):
         if leaf:
             k0 = leaf[0]
             tr = traffic.get(k0["kernel"]) if traffic else None
-            if k0.get("flops_per_launch"):
+            if k0.get("flops_per_launch") and k0["kernel"] != "k_pitch_frames":     # (k_pitch_frames carries fp64 VALU flops: HBM form below + its fp64 rate)
                 ach = k0["flops_per_launch"] / (k0["avg_ms"] * 1e-3) / 1e12
                 roofline = {"kernel": k0["kernel"], "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": tr, "avg_launch_ms": k0["avg_ms"],
@@ -545,6 +545,9 @@ def run_rank(args, world, rank, local_rank):
                             "note": "dominant kernel by device time per step; achieved = the algorithmic bytes of its stage (SURVEY.md 8d: "
                                     "PCM in + results out, intermediates excluded) / this kernel's own mean launch duration.  The F0 kernels are "
                                     "fp64-VALU bound (about 1e3 flop per algorithmic byte): their HBM fraction is small by construction"}
+                if k0.get("achieved_tflops") and k0["kernel"] == "k_pitch_frames":
+                    roofline.update({"achieved_tflops_f64": k0["achieved_tflops"], "peak_tflops_f64": FP64_VECTOR_PEAK_TFLOPS,
+                                     "frac_f64": k0["achieved_tflops"] / FP64_VECTOR_PEAK_TFLOPS})
         floor = None
         if wdims:
             floor_ms = flop / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
@@ -553,7 +556,7 @@ def run_rank(args, world, rank, local_rank):
         info = eng.device_info()
         what = ("energy/gate + BS.1770 LUFS + Praat-AC F0 150-600 Hz (path finder, voiced median) + STFT-dB 1024/256"
                 + (f" + log-mel + Whisper-{args.whisper_model} encoder + teacher-forced decoder / cross-attention DTW alignment "
-                   "(synthetic weights and token ids, bf16 MFMA)" if wdims else ""))
+                   f"(synthetic weights and token ids, {eng.whisper_operands} MFMA)" if wdims else ""))
         print(json.dumps({
             "metric": ("audio-seconds/sec prosody+align throughput, 16 kHz French" if wdims
                        else "audio-seconds/sec prosody throughput (no alignment leg), 16 kHz French"),
