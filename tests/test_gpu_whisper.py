@@ -239,6 +239,35 @@ def test_cached_and_uncached_decoding_agree(engine):
         assert (body[:-1] if body and body[-1] == rules["eot"] else body) == w
 
 
+def test_cached_decoding_with_long_prompts_agrees(engine):
+    """Prompts of 130-230 tokens (``condition_on_previous_text`` at its longest) on a decoder with the real 448-token text context: the
+    self-attention of an incremental step then takes the kernel's general path (more than 128 keys: V^T rows read in 512-key pieces by
+    the lanes that hold live keys, the new key and value attended to from registers) instead of the few-key one; cached and uncached
+    decoding agree as for short prompts."""
+    from tests.test_whisper_hf_crosscheck import _greedy_gold
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    _, rules = _greedy_gold()
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=448, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=77), WW.greedy_test_decoder_weights(tdims, seed=79)
+    use = [synth.synth_clip(i, seconds=4.0) for i in range(4)]
+    engine.upload(use, 16000)
+    engine.logmel_run(80)
+    engine.whisper_load(edims, WW.pack(We, edims))
+    engine.whisper_encode_run()
+    engine.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+    init = _greedy_gold()[0]["initial"].tolist()
+    n = len(use)
+    prompts = [[(17 * k + 3 * i) % 200 + 5 for k in range(130 + 33 * (i % 4))] + list(init) for i in range(n)]
+    begins = [len(p) for p in prompts]
+    cached, lp_c, _ = DEC.decode_batch(engine, tdims["n_vocab"], prompts, begins, rules, sample_len=14)
+    plain, lp_p, _ = DEC.decode_batch(engine, tdims["n_vocab"], prompts, begins, rules, sample_len=14, no_cache=True)
+    agree = [next((k for k, (a, b) in enumerate(zip(x, y)) if a != b), min(len(x), len(y))) for x, y in zip(cached, plain)]
+    assert min(agree) >= 4 and sum(a == min(len(x), len(y)) for a, x, y in zip(agree, cached, plain)) >= 2, agree
+    for a, x, y in zip(agree, lp_c, lp_p):
+        assert np.allclose(x[:a], y[:a], atol=0.05)
+
+
 def test_logmel_windows_of_a_long_recording(engine):
     """Recordings longer than 30 s (segment_ph6 of the demo data runs 37.2 s): the window whisper.transcribe takes at a
     seek position is a slice of the log-mel of the WHOLE recording, clamped with the global maximum."""
