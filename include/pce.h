@@ -33,6 +33,10 @@
 extern "C" {
 #endif
 
+/* libpce.so is built with -fvisibility=hidden: the functions declared between this pragma and its pop are the library's ONLY exported
+ * symbols (tests/test_abi_and_shard.py compares `nm -D` with this header, both ways). */
+#pragma GCC visibility push(default)
+
 #define PCE_API_VERSION 1
 
 typedef struct pce_ctx pce_ctx;
@@ -171,6 +175,13 @@ typedef struct pce_pitch_summary {
 int pce_pitch_plan(pce_ctx *ctx, const pce_pitch_params *p, const pce_slice *slices, int32_t n_slices,
                    int64_t *frame_offsets, int32_t *status);
 int pce_pitch_run(pce_ctx *ctx, const pce_pitch_params *p, const pce_slice *slices, int32_t n_slices);
+/* How k_pitch_refine searches a candidate's maximum (Praat: NUMimproveMaximum -> NUMminimize_brent on the sinc-interpolated
+ * autocorrelation).  PCE_REFINE_SEEDED (default): successive parabolic interpolation seeded with the three samples around the peak,
+ * Praat's own iterates only where the two could differ (within 0.03 lag of a sample, or when a safeguard trips): candidates agree with
+ * Praat's to ~1e-6 relative.  PCE_REFINE_PRAAT: NUMminimize_brent's iterates replayed for every candidate (iterate for iterate; about
+ * 2.5 x the refinement time).  The environment variable PCE_PITCH_REFINE=praat at pce_create selects the second as the context's default. */
+enum { PCE_REFINE_SEEDED = 0, PCE_REFINE_PRAAT = 1 };
+int pce_pitch_set_refine(pce_ctx *ctx, int32_t mode);
 /* f0 / strength: ragged [frame_offsets[n_slices]], either may be NULL. */
 int pce_pitch_fetch(pce_ctx *ctx, double *f0, double *strength, pce_pitch_summary *summary /* n_slices */);
 
@@ -241,7 +252,7 @@ int pce_selftest_gemm(pce_ctx *ctx, const uint16_t *A, const uint16_t *B, const 
 /* Self-test of the attention kernel (64-wide heads; csrc/pce_whisper.hip k_attention_lean) on host arrays of bf16 bit patterns: clips x
  * heads independent problems, q [clips][q_len][heads * 64], k and v [clips][k_len][heads * 64], out like q; softmax(q k^T / 8) v with the
  * causal mask when causal != 0.  mode 0: the kernel as the engine runs it (fixed softmax reference, exact fallback), 1: its exact
- * path only, 2: the round-1 kernel.  *fell_back (may be NULL): number of workgroups that had to take the exact path (mode 0). */
+ * path only.  *fell_back (may be NULL): number of workgroups that had to take the exact path (mode 0). */
 int pce_selftest_attention(pce_ctx *ctx, const uint16_t *q, const uint16_t *k, const uint16_t *v, int32_t clips, int32_t heads, int32_t q_len,
                            int32_t k_len, int32_t causal, int32_t mode, uint16_t *out, int32_t *fell_back);
 int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
@@ -397,6 +408,8 @@ int pce_profile_get(pce_ctx *ctx, int kernel_id, double *total_ms, int64_t *laun
  * (2 M N K of a GEMM launch, 4 T^2 d of an attention launch; 0 for ids that do not count) */
 int pce_profile_get_work(pce_ctx *ctx, int kernel_id, double *flops);
 const char *pce_kernel_name(int kernel_id);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

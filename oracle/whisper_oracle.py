@@ -9,8 +9,13 @@ exercised with fixed-seed synthetic weights.  Pinned against an independent impl
 same network: tests/golden/whisper_hf_tiny.npz holds log-mel columns, encoder rows, teacher-forced
 decoder logits and a cross-attention map produced by the installed transformers port
 (tests/golden/make_goldens_whisper_hf.py; tests/test_whisper_hf_crosscheck.py).  The stage of
-``find_alignment`` after the attention logits (normalise, median filter, mean, DTW) has no such
-check: parity unpinned.
+``find_alignment`` after the attention logits (head selection, softmax, std / mean normalisation,
+median filter, head mean, DTW, token jump times) is pinned to transformers'
+``_extract_token_timestamps`` on the full 30 s window (tests/golden/whisper_hf_align.npz, made by
+tests/golden/make_goldens_whisper_hf_align.py, which says how the two recipes differ in their row
+crop and why the function is driven directly); with a crop to ``num_frames // 2`` columns
+openai-whisper cuts the logits before the softmax and transformers the probabilities after it:
+that form stays a restatement.
 """
 import numpy as np
 import torch
@@ -157,7 +162,7 @@ def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
 
 
 def find_alignment(tokens, enc_out: np.ndarray, W: dict, dims: dict, num_frames: int, sot_len: int, head_mask=None,
-                   medfilt_width: int = 7, qk_scale: float = 1.0, want_internal: bool = False):
+                   medfilt_width: int = 7, qk_scale: float = 1.0, want_internal: bool = False, want_matrix: bool = False):
     """TextDecoder.forward (teacher forced) + the cross-attention / DTW part of timing.py find_alignment.
     Returns (cost matrix fed to the DTW, text_indices, time_indices)."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
@@ -210,9 +215,13 @@ def find_alignment(tokens, enc_out: np.ndarray, W: dict, dims: dict, num_frames:
     weights = (weights - mean) / std
     weights = median_filter(weights, medfilt_width)
     matrix = weights.mean(axis=0)
+    if want_matrix:                       # the normalised, filtered, head-averaged matrix over ALL rows (pinned: tests/golden/whisper_hf_align.npz)
+        full = matrix.numpy().copy()
     matrix = matrix[sot_len:-1]
     cost = (-matrix).double().numpy()
     ti, tj = dtw_path(cost)
+    if want_matrix:
+        return cost, ti, tj, full
     return cost, ti, tj
 
 

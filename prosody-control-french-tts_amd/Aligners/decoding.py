@@ -47,13 +47,15 @@ def greedy_decode(engine, n_vocab: int, initial_tokens, rules: dict, sample_len:
 
 
 def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, sample_len: int, temperature: float = 0.0, seed: int = 0,
-                 active=None, no_cache: bool = False, device_loop: bool = True):
+                 active=None, no_cache: bool = False, device_loop: bool = True, n_text_ctx: int = None):
     """``greedy_decode`` with one prompt per clip (``condition_on_previous_text`` gives every recording its own) and an
     optional temperature (GreedyDecoder at temperature t: one sample per step from softmax(filtered logits / t)).
     ``active[i]`` False: the clip is left alone (it reads as ended from the first step on).
     -> (sampled tokens per clip, end-of-text cut off; their log-probabilities per clip; sum_logprobs [clips]).
     ``device_loop`` (default): the step loop runs inside the engine (``pce_whisper_decode_loop``: prompts up once, results down
-    once); False: one ``whisper_decode_step_ex`` round trip per step -- the form the device loop is checked against."""
+    once); False: one ``whisper_decode_step_ex`` round trip per step -- the form the device loop is checked against.
+    A sequence that fills the text context (``n_text_ctx``; prompt of up to 227 tokens + 224 sampled ones can exceed 448) stops there and keeps
+    what it has, as DecodingTask._main_loop breaks on ``tokens.shape[-1] > n_ctx``: the other sequences of the batch go on."""
     n = engine.whisper_num_encoded()
     eot = rules["eot"]
     active = [True] * n if active is None else list(active)
@@ -72,7 +74,9 @@ def decode_batch(engine, n_vocab: int, prompts, sample_begins, rules: dict, samp
                     lps[i].append(float(lp[i, step]))
         sample_len = 0                                              # (the loop below has nothing left to do)
     for _ in range(sample_len):
-        nxt, lp, _ = engine.whisper_decode_step_ex(seqs, begins, eot, rules["timestamp_begin"], mask, rules.get("max_initial_timestamp_index"),
+        # (a sequence beyond the context is handed over as ended: its last entry reads end-of-text, exactly what the device loop's table holds)
+        send = seqs if n_text_ctx is None else [s if len(s) <= n_text_ctx else s[:n_text_ctx - 1] + [eot] for s in seqs]
+        nxt, lp, _ = engine.whisper_decode_step_ex(send, begins, eot, rules["timestamp_begin"], mask, rules.get("max_initial_timestamp_index"),
                                                    temperature=temperature, seed=seed, no_cache=no_cache)
         for i in range(n):
             ended = seqs[i][-1] == eot and len(seqs[i]) > begins[i]

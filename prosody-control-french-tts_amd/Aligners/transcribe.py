@@ -232,8 +232,8 @@ def transcribe_batch(engine, model, tokenizer, clips: Sequence[np.ndarray], opti
         final = [None] * n
         todo = list(active)
         for t in opt.temperature:
-            toks, lps, sums = DEC.decode_batch(engine, n_vocab, prompts, begins, rules, min(sample_len, n_text_ctx - max(begins)), temperature=float(t),
-                                               seed=opt.seed + int(round(t * 1000)) + 7919 * max(seeks), active=todo)
+            toks, lps, sums = DEC.decode_batch(engine, n_vocab, prompts, begins, rules, sample_len, temperature=float(t),
+                                               seed=opt.seed + int(round(t * 1000)) + 7919 * max(seeks), active=todo, n_text_ctx=n_text_ctx)
             for i in range(n):
                 if not todo[i]:
                     continue

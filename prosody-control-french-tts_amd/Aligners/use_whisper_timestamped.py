@@ -376,91 +376,92 @@ def main(audio_path, out_path, whisper_model="medium", device=None, logger=None)
             names = names[lo:hi]
             N = len(names)
             logger.info(f"rank {rank}/{world}: fichiers {lo}..{hi - 1}")
-        OP = os.path.join(out_path + "_transcription")
-        os.makedirs(OP, exist_ok=True)
         textgrid_dir = out_path
-        os.makedirs(textgrid_dir, exist_ok=True)
+        # the rank-local part: whatever happens in it, every rank leaves it through the same status barrier, so that every rank's
+        # TextGrids exist before the folders are matched and a failure on one rank fails the call on all of them (sys.exit(1) below)
+        with shard.agreed():
+            OP = os.path.join(out_path + "_transcription")
+            os.makedirs(OP, exist_ok=True)
+            os.makedirs(textgrid_dir, exist_ok=True)
 
-        # ---- the inline noise gate (:579-621) for all files in one pass
-        paths = [os.path.join(audio_path, f"{n}.wav") for n in names]
-        decoded = {}
-        for i, p in enumerate(paths):
+            # ---- the inline noise gate (:579-621) for all files in one pass
+            paths = [os.path.join(audio_path, f"{n}.wav") for n in names]
+            decoded = {}
+            for i, p in enumerate(paths):
+                try:
+                    decoded[i] = H.decode_wav(p)
+                except Exception as e:                                           # noqa: BLE001
+                    logger.error(f"Erreur lors de l'analyse audio de {names[i]}: {e}")     # the reference continues normally
             try:
-                decoded[i] = H.decode_wav(p)
-            except Exception as e:                                           # noqa: BLE001
-                logger.error(f"Erreur lors de l'analyse audio de {names[i]}: {e}")     # the reference continues normally
-        try:
-            gate = _gate(transcriber.engine, decoded, paths)
-        except Exception as e:                                               # noqa: BLE001
-            logger.error(f"Erreur lors de l'analyse audio: {e}")
-            gate = {}
-        processed, count, todo = [], 0, []
-        for i, n in enumerate(names):
-            g = gate.get(i)
-            if g is not None and (g[3] > 0.95 or g[2] < 100):
-                logger.warning(f"Fichier {n} détecté comme bruit/silence (RMS={g[2]}, silence_ratio={g[3]:.2f})")
-                with open(os.path.join(OP, f"{n}.txt"), "w", encoding="utf-8") as f:
-                    f.write("...")
-                write_textgrid(_placeholder_grid(1.0), os.path.join(textgrid_dir, f"{n}.TextGrid"))
-                processed.append(n); count += 1
-            else:
-                todo.append(i)
+                gate = _gate(transcriber.engine, decoded, paths)
+            except Exception as e:                                               # noqa: BLE001
+                logger.error(f"Erreur lors de l'analyse audio: {e}")
+                gate = {}
+            processed, count, todo = [], 0, []
+            for i, n in enumerate(names):
+                g = gate.get(i)
+                if g is not None and (g[3] > 0.95 or g[2] < 100):
+                    logger.warning(f"Fichier {n} détecté comme bruit/silence (RMS={g[2]}, silence_ratio={g[3]:.2f})")
+                    with open(os.path.join(OP, f"{n}.txt"), "w", encoding="utf-8") as f:
+                        f.write("...")
+                    write_textgrid(_placeholder_grid(1.0), os.path.join(textgrid_dir, f"{n}.TextGrid"))
+                    processed.append(n); count += 1
+                else:
+                    todo.append(i)
 
-        # ---- transcription of everything that passed, as resident batches
-        results = transcriber.process_audio_batch([paths[i] for i in todo]) if todo else []
-        for i, result in zip(todo, results):
-            n = names[i]
-            json_file, txt_file = os.path.join(OP, f"{n}.json"), os.path.join(OP, f"{n}.txt")
-            try:
-                if isinstance(result, Exception):
-                    raise result
-                raw_json_dir = Path(out_path + "_raw_json"); raw_json_dir.mkdir(parents=True, exist_ok=True)
-                raw_json_path = raw_json_dir / f"{n}.raw.json"
-                raw_json_path.write_text(json.dumps(result, ensure_ascii=False, indent=2), encoding="utf-8")
-                raw_tg_dir = Path(out_path + "_textgrid_raw"); raw_tg_dir.mkdir(parents=True, exist_ok=True)
-                write_textgrid(json_to_textgrid(str(raw_json_path), logger), str(raw_tg_dir / f"{n}.TextGrid"))
-                for segment in result["segments"]:
-                    segment["text"] = transcriber.clean_text(segment["text"])
-                    for word in segment["words"]:
-                        word["text"] = transcriber.clean_text(word["text"])
-                transcriber.save_results(result, json_file)
-                clean = transcriber.clean_text(" ".join(seg["text"] for seg in result["segments"]))
-                with open(txt_file, "w", encoding="utf-8") as f:
-                    f.write(clean)
-                write_textgrid(json_to_textgrid(json_file, logger), os.path.join(textgrid_dir, f"{n}.TextGrid"))
-                logger.info(f"TextGrid created: {os.path.join(textgrid_dir, f'{n}.TextGrid')}")
-                processed.append(n)
-            except Exception as e:                                           # noqa: BLE001
-                logger.error(f"Error during file processing {n}: {e}")
-                logger.error("".join(traceback.format_exception(type(e), e, e.__traceback__)))
-                logger.warning("Moving to the next file...")
-                continue
-            count += 1
-            logger.info(f"Progression: {count}/{N} Files processed successfully")
-        logger.info(f"Processing completed: {count}/{N} ")
+            # ---- transcription of everything that passed, as resident batches
+            results = transcriber.process_audio_batch([paths[i] for i in todo]) if todo else []
+            for i, result in zip(todo, results):
+                n = names[i]
+                json_file, txt_file = os.path.join(OP, f"{n}.json"), os.path.join(OP, f"{n}.txt")
+                try:
+                    if isinstance(result, Exception):
+                        raise result
+                    raw_json_dir = Path(out_path + "_raw_json"); raw_json_dir.mkdir(parents=True, exist_ok=True)
+                    raw_json_path = raw_json_dir / f"{n}.raw.json"
+                    raw_json_path.write_text(json.dumps(result, ensure_ascii=False, indent=2), encoding="utf-8")
+                    raw_tg_dir = Path(out_path + "_textgrid_raw"); raw_tg_dir.mkdir(parents=True, exist_ok=True)
+                    write_textgrid(json_to_textgrid(str(raw_json_path), logger), str(raw_tg_dir / f"{n}.TextGrid"))
+                    for segment in result["segments"]:
+                        segment["text"] = transcriber.clean_text(segment["text"])
+                        for word in segment["words"]:
+                            word["text"] = transcriber.clean_text(word["text"])
+                    transcriber.save_results(result, json_file)
+                    clean = transcriber.clean_text(" ".join(seg["text"] for seg in result["segments"]))
+                    with open(txt_file, "w", encoding="utf-8") as f:
+                        f.write(clean)
+                    write_textgrid(json_to_textgrid(json_file, logger), os.path.join(textgrid_dir, f"{n}.TextGrid"))
+                    logger.info(f"TextGrid created: {os.path.join(textgrid_dir, f'{n}.TextGrid')}")
+                    processed.append(n)
+                except Exception as e:                                           # noqa: BLE001
+                    logger.error(f"Error during file processing {n}: {e}")
+                    logger.error("".join(traceback.format_exception(type(e), e, e.__traceback__)))
+                    logger.warning("Moving to the next file...")
+                    continue
+                count += 1
+                logger.info(f"Progression: {count}/{N} Files processed successfully")
+            logger.info(f"Processing completed: {count}/{N} ")
 
-        problematic = [n for n in names if n not in processed]
-        if problematic:
-            logger.warning(f"{len(problematic)}  Problematic files identified:")
-            for n in problematic:
-                logger.warning(f"  - {n}.wav")
-                write_textgrid(_placeholder_grid(1.0), os.path.join(textgrid_dir, f"{n}.TextGrid"))
-                with open(os.path.join(OP, f"{n}.txt"), "w", encoding="utf-8") as f:
-                    f.write("...")
+            problematic = [n for n in names if n not in processed]
+            if problematic:
+                logger.warning(f"{len(problematic)}  Problematic files identified:")
+                for n in problematic:
+                    logger.warning(f"  - {n}.wav")
+                    write_textgrid(_placeholder_grid(1.0), os.path.join(textgrid_dir, f"{n}.TextGrid"))
+                    with open(os.path.join(OP, f"{n}.txt"), "w", encoding="utf-8") as f:
+                        f.write("...")
 
-        if world > 1:
-            shard.barrier()                                                  # every rank's TextGrids exist before the folders are matched
-            if rank != 0:
-                return
-        base_path = os.path.dirname(audio_path)
-        if "_microsoft" in base_path:
-            natural_dir = os.path.join(os.path.dirname(base_path), os.path.basename(base_path).replace("_microsoft", ""), "WhisperTS_textgrid_files")
-            if os.path.exists(natural_dir):
-                create_matching_textgrids(natural_dir, textgrid_dir, logger)
-        else:
-            synthetic_dir = os.path.join(os.path.dirname(base_path), os.path.basename(base_path) + "_microsoft", "WhisperTS_textgrid_files")
-            if os.path.exists(synthetic_dir):
-                create_matching_textgrids(textgrid_dir, synthetic_dir, logger)
+        with shard.agreed(only_rank=0) as sec:                               # (ranks other than 0 leave when the folders are matched, not before)
+            if sec.mine:
+                base_path = os.path.dirname(audio_path)
+                if "_microsoft" in base_path:
+                    natural_dir = os.path.join(os.path.dirname(base_path), os.path.basename(base_path).replace("_microsoft", ""), "WhisperTS_textgrid_files")
+                    if os.path.exists(natural_dir):
+                        create_matching_textgrids(natural_dir, textgrid_dir, logger)
+                else:
+                    synthetic_dir = os.path.join(os.path.dirname(base_path), os.path.basename(base_path) + "_microsoft", "WhisperTS_textgrid_files")
+                    if os.path.exists(synthetic_dir):
+                        create_matching_textgrids(textgrid_dir, synthetic_dir, logger)
     except Exception as e:
         logger.error(f"Error in principal code: {e}")
         logger.error(traceback.format_exc())

@@ -277,6 +277,19 @@ class _Planner(MeasurementSource):
         return self.em.part_duration(kind, segment, t0, t1)
 
 
+class _FailedSource(MeasurementSource):
+    """Stands in for the measurements of a rank whose local stage (decode / plan / GPU passes) raised: every query re-raises that
+    error, inside ``SsmlTagger.run_sharded``'s guarded section, which still enters the collective."""
+
+    def __init__(self, error):
+        self.error = error
+
+    def median_pitch(self, segment, t0=0.0, t1=None): raise self.error
+    def lufs(self, kind, segment, t0=0.0, t1=None): raise self.error
+    def duration(self, kind, segment): raise self.error
+    def part_duration(self, kind, segment, t0=0.0, t1=None): raise self.error
+
+
 class AudioPipeline:
     def __init__(self, name, cfg, base: Optional[Path] = None, engine: Optional[ProsodyEngine] = None, nlp=None):
         self.name, self.cfg = name, cfg
@@ -300,7 +313,7 @@ class AudioPipeline:
         # "cuda:3" names the device; a bare "cuda" under a one-process-per-GPU launcher means this rank's own GPU (LOCAL_RANK)
         self.device_index = (int(str(self.whisper_device).split(":")[1]) if ":" in str(self.whisper_device)
                              else int(os.environ.get("LOCAL_RANK", "0")))
-        self._engine, self._nlp = engine, nlp
+        self._engine, self._nlp, self._refine_set = engine, nlp, False
         self.results_dir.mkdir(parents=True, exist_ok=True)
         wanted = cfg.get("steps_to_run") or STEP_NAMES
         unknown = [n for n in wanted if n not in STEP_NAMES]
@@ -313,7 +326,10 @@ class AudioPipeline:
 
     def _get_engine(self) -> ProsodyEngine:
         if self._engine is None:
-            self._engine = ProsodyEngine(self.device_index)
+            from .engine import get_default_engine
+            self._engine = get_default_engine(self.device_index)             # ONE context per process: the aligner's steps use the same one
+        if self.cfg.get("pitch_refine") and not self._refine_set:            # additive key: "seeded" (default) | "praat" (Praat's own iterates)
+            self._engine.pitch_set_refine(self.cfg["pitch_refine"]); self._refine_set = True
         return self._engine
 
     # ------------------------------------------------------------------ the hot step
@@ -339,22 +355,25 @@ class AudioPipeline:
             # (Code/audioPipeline.py:364-424, :592-602).  Rank 0 writes the three tables.
             lo, hi = shard.shard_range(len(segments), rank, world)
             mine = segments[lo:hi]
-            local_files = {k: v for k, v in files.items() if k[1] in {sg.name for sg in mine}}
-            first_rate = None
             try:
-                first_rate = H.decode_wav(wavs[0])[0]                        # the voice's first natural file fixes the segment-level meter (:372)
-            except H.CouldntDecodeError:
-                pass
-            em = EngineMeasurements(self._get_engine(), local_files, first_nat_rate=first_rate)
-            planner = _Planner(em)
-            tagger.segment_statistics(mine, planner); tagger.syntagme_measurements(mine, planner)     # pass 1 over the local block: collect the queries
-            em.run()
+                local_files = {k: v for k, v in files.items() if k[1] in {sg.name for sg in mine}}
+                first_rate = None
+                try:
+                    first_rate = H.decode_wav(wavs[0])[0]                    # the voice's first natural file fixes the segment-level meter (:372)
+                except H.CouldntDecodeError:
+                    pass
+                em = EngineMeasurements(self._get_engine(), local_files, first_nat_rate=first_rate)
+                planner = _Planner(em)
+                tagger.segment_statistics(mine, planner); tagger.syntagme_measurements(mine, planner)     # pass 1 over the local block: collect the queries
+                em.run()
+            except Exception as e:                                           # noqa: BLE001
+                em = _FailedSource(e)                                        # run_sharded flags this rank's block in the ONE collective: all ranks fail together
             res = tagger.run_sharded(segments, em, rank, world, shard.allgather_records)
-            if rank == 0:
-                res.bdd_ssml.to_csv(self.bdd_ssml_csv, index=False)
-                res.bdd_syntagme_ssml.to_csv(self.bdd_syntagme_ssml_csv, index=False)
-                res.bdd_syntagme_for_synth.to_csv(self.bdd_syntagme_synth_csv, index=False)
-            shard.barrier()                                                  # the tables exist when any rank returns
+            with shard.agreed(only_rank=0) as sec:                           # the tables exist (or every rank knows they do not) when any rank returns
+                if sec.mine:
+                    res.bdd_ssml.to_csv(self.bdd_ssml_csv, index=False)
+                    res.bdd_syntagme_ssml.to_csv(self.bdd_syntagme_ssml_csv, index=False)
+                    res.bdd_syntagme_for_synth.to_csv(self.bdd_syntagme_synth_csv, index=False)
             return res
         em = EngineMeasurements(self._get_engine(), files)
         tagger.run(segments, _Planner(em))         # pass 1: collect every query (they depend on the TextGrids only)
@@ -388,21 +407,29 @@ class AudioPipeline:
         txt_folder = self.voice_dir / "transcription"
         txt_raw_folder = self.voice_dir / "transcription_raw"
         raw_json_dir = Path(str(tg_folder) + "_raw_json")
-        for d in (tg_folder, txt_folder, self.voice_dir / "WhisperTS_textgrid_files_transcription", txt_raw_folder, raw_json_dir):
-            shutil.rmtree(d, ignore_errors=True)
-        for d in (tg_folder, txt_folder, txt_raw_folder, raw_json_dir):
-            d.mkdir(parents=True, exist_ok=True)
+        from . import shard
+        # Under one process per GPU the folders are shared: rank 0 alone resets them BEFORE any rank's aligner writes into them, and rank 0
+        # alone post-processes AFTER every rank's files exist (A.main ends on a status barrier); each section is left through
+        # ``shard.agreed`` so that a failure on one rank fails the step on all of them.
+        with shard.agreed(only_rank=0) as sec:
+            if sec.mine:
+                for d in (tg_folder, txt_folder, self.voice_dir / "WhisperTS_textgrid_files_transcription", txt_raw_folder, raw_json_dir):
+                    shutil.rmtree(d, ignore_errors=True)
+                for d in (tg_folder, txt_folder, txt_raw_folder, raw_json_dir):
+                    d.mkdir(parents=True, exist_ok=True)
         self._whisper_main(audio_folder, tg_folder)
-        for js in raw_json_dir.glob("*.raw.json"):
-            data = json.loads(js.read_text(encoding="utf-8"))
-            (txt_raw_folder / js.name.replace(".raw.json", ".txt")).write_text(" ".join(seg["text"] for seg in data["segments"]), encoding="utf-8")
-        for wav in Path(audio_folder).glob("*.wav"):
-            raw_txt = txt_raw_folder / f"{wav.stem}.txt"
-            if not raw_txt.exists():
-                raw_txt.write_text("...", encoding="utf-8")
-        save_clean_transcriptions_from_textgrids(tg_folder, txt_folder)
-        for txt in Path(txt_folder).glob("*.txt"):
-            txt.write_text(remove_spurious_commas(txt.read_text(encoding="utf-8")), encoding="utf-8")
+        with shard.agreed(only_rank=0) as sec:
+            if sec.mine:
+                for js in raw_json_dir.glob("*.raw.json"):
+                    data = json.loads(js.read_text(encoding="utf-8"))
+                    (txt_raw_folder / js.name.replace(".raw.json", ".txt")).write_text(" ".join(seg["text"] for seg in data["segments"]), encoding="utf-8")
+                for wav in Path(audio_folder).glob("*.wav"):
+                    raw_txt = txt_raw_folder / f"{wav.stem}.txt"
+                    if not raw_txt.exists():
+                        raw_txt.write_text("...", encoding="utf-8")
+                save_clean_transcriptions_from_textgrids(tg_folder, txt_folder)
+                for txt in Path(txt_folder).glob("*.txt"):
+                    txt.write_text(remove_spurious_commas(txt.read_text(encoding="utf-8")), encoding="utf-8")
 
     def final_transcribe(self):
         """Code/audioPipeline.py:856-892: the aligner over ``results/<voice>/OUT.wav``, results moved next to it."""
@@ -412,15 +439,20 @@ class AudioPipeline:
         if not out_wav.exists():
             logging.error(f"No OUT.wav found at {out_wav}")
             return
+        from . import shard
         temp_dir = self.results_dir / "final_whisper"
         tg_dir, txt_dir = temp_dir / "WhisperTS_textgrid_files", temp_dir / "transcription_final"
-        tg_dir.mkdir(parents=True, exist_ok=True); txt_dir.mkdir(parents=True, exist_ok=True)
+        with shard.agreed(only_rank=0) as sec:
+            if sec.mine:
+                tg_dir.mkdir(parents=True, exist_ok=True); txt_dir.mkdir(parents=True, exist_ok=True)
         self._whisper_main(out_wav.parent, tg_dir)
-        save_clean_transcriptions_from_textgrids(tg_dir, txt_dir)
-        for tg in tg_dir.glob("*.TextGrid"):
-            tg.rename(self.results_dir / tg.name)
-        for txt in txt_dir.glob("*.txt"):
-            txt.rename(self.results_dir / txt.name)
+        with shard.agreed(only_rank=0) as sec:                               # (every rank would rename the same files: rank 0 does, the others wait)
+            if sec.mine:
+                save_clean_transcriptions_from_textgrids(tg_dir, txt_dir)
+                for tg in tg_dir.glob("*.TextGrid"):
+                    tg.rename(self.results_dir / tg.name)
+                for txt in txt_dir.glob("*.txt"):
+                    txt.rename(self.results_dir / txt.name)
         logging.info(f"Final transcription files saved in {self.results_dir}")
 
     # ------------------------------------------------------------------ break prediction (BASELINE.json configs[4]: additive, not a reference step)
@@ -438,49 +470,59 @@ class AudioPipeline:
         rank 0 writes ``results/<voice>/BDD_breaks.csv`` (segment, word_index, word, break)."""
         from . import bert_weights as BW, shard
         from .Preprocessing import break_bert as BB
-        eng = self._get_engine()
-        if weights is None and self.cfg.get("break_bert_weights"):
-            path = str(self.cfg["break_bert_weights"])
-            if path.endswith(".npz"):
-                with np.load(path) as z:
-                    weights = {k: z[k] for k in z.files}
-            else:
-                from safetensors.numpy import load_file
-                weights = load_file(path)
-        if weights is not None:
-            if dims is None:
-                d = weights["bert.embeddings.word_embeddings.weight"].shape
-                n_layer = 1 + max(int(k.split(".")[3]) for k in weights if k.startswith("bert.encoder.layer."))
-                dims = dict(n_vocab=int(d[0]), n_pos=int(weights["bert.embeddings.position_embeddings.weight"].shape[0]),
-                            n_type=int(weights["bert.embeddings.token_type_embeddings.weight"].shape[0]), n_state=int(d[1]), n_head=int(d[1]) // 64,
-                            n_layer=n_layer, n_labels=int(weights["classifier.weight"].shape[0]))
-            eng.bert_load(dims, BW.pack(weights, dims))
-        if word_piecer is None:
-            vocab = self.cfg.get("break_bert_vocab")
-            if not vocab:
-                raise FileNotFoundError('break prediction needs the checkpoint\'s WordPiece vocabulary: set "break_bert_vocab" (vocab.txt) or pass word_piecer')
-            from transformers import BertTokenizer
-            tok = BertTokenizer(str(vocab), do_lower_case=True)
-            cls_id, sep_id = tok.cls_token_id, tok.sep_token_id
-            word_piecer = lambda w: tok.convert_tokens_to_ids(tok.tokenize(w))
         txts = sorted(self.transcription_dir.glob("*.txt"), key=lambda p: segment_sort_key(p.stem))
         words = [t.read_text(encoding="utf-8").split() for t in txts]
         rank, world = shard.rank_world()
         lo, hi = shard.shard_range(len(txts), rank, world)
-        mine = [[word_piecer(w) for w in ws] for ws in words[lo:hi]]
-        local = BB.predict_breaks(eng, mine, cls_id, sep_id) if mine else []
         width = max([len(ws) for ws in words] + [1])
-        rec = np.full((len(local), width), -1.0)
-        for i, lab in enumerate(local):
-            rec[i, :len(lab)] = lab
         counts = [b - a for a, b in (shard.shard_range(len(txts), r, world) for r in range(world))]
-        allrec = shard.allgather_records(rec, counts)
+        local_error = None
+        try:                                                                 # everything that can fail on ONE rank (device, weight file, vocabulary)
+            eng = self._get_engine()
+            if weights is None and self.cfg.get("break_bert_weights"):
+                path = str(self.cfg["break_bert_weights"])
+                if path.endswith(".npz"):
+                    with np.load(path) as z:
+                        weights = {k: z[k] for k in z.files}
+                else:
+                    from safetensors.numpy import load_file
+                    weights = load_file(path)
+            if weights is not None:
+                if dims is None:
+                    d = weights["bert.embeddings.word_embeddings.weight"].shape
+                    n_layer = 1 + max(int(k.split(".")[3]) for k in weights if k.startswith("bert.encoder.layer."))
+                    dims = dict(n_vocab=int(d[0]), n_pos=int(weights["bert.embeddings.position_embeddings.weight"].shape[0]),
+                                n_type=int(weights["bert.embeddings.token_type_embeddings.weight"].shape[0]), n_state=int(d[1]), n_head=int(d[1]) // 64,
+                                n_layer=n_layer, n_labels=int(weights["classifier.weight"].shape[0]))
+                eng.bert_load(dims, BW.pack(weights, dims))
+            if word_piecer is None:
+                vocab = self.cfg.get("break_bert_vocab")
+                if not vocab:
+                    raise FileNotFoundError('break prediction needs the checkpoint\'s WordPiece vocabulary: set "break_bert_vocab" (vocab.txt) or pass word_piecer')
+                from transformers import BertTokenizer
+                tok = BertTokenizer(str(vocab), do_lower_case=True)
+                cls_id, sep_id = tok.cls_token_id, tok.sep_token_id
+                word_piecer = lambda w: tok.convert_tokens_to_ids(tok.tokenize(w))
+            mine = [[word_piecer(w) for w in ws] for ws in words[lo:hi]]
+            max_len = min(BW.MAX_LENGTH, int(dims["n_pos"])) if dims else BW.MAX_LENGTH       # (pause_bert.py:16; a smaller checkpoint truncates at its own table)
+            local = BB.predict_breaks(eng, mine, cls_id, sep_id, max_len) if mine else []
+            rec = np.full((len(local), width), -1.0)
+            for i, lab in enumerate(local):
+                rec[i, :len(lab)] = lab
+        except Exception as e:                                               # noqa: BLE001  (the rank still enters the ONE collective, flagged)
+            local_error, rec = e, np.zeros((0, width))
+        try:
+            allrec = shard.allgather_records(rec, counts, failed=local_error is not None)
+        except shard.PeerFailure:
+            if local_error is not None:
+                raise local_error
+            raise
         labels = [[int(v) for v in allrec[i, :len(ws)]] for i, ws in enumerate(words)]
-        if rank == 0:
-            import pandas as pd
-            rows = [{"segment": t.stem, "word_index": k, "word": w, "break": b} for t, ws, lab in zip(txts, words, labels) for k, (w, b) in enumerate(zip(ws, lab))]
-            pd.DataFrame(rows, columns=["segment", "word_index", "word", "break"]).to_csv(self.results_dir / "BDD_breaks.csv", index=False)
-        shard.barrier()
+        with shard.agreed(only_rank=0) as sec:
+            if sec.mine:
+                import pandas as pd
+                rows = [{"segment": t.stem, "word_index": k, "word": w, "break": b} for t, ws, lab in zip(txts, words, labels) for k, (w, b) in enumerate(zip(ws, lab))]
+                pd.DataFrame(rows, columns=["segment", "word_index", "word", "break"]).to_csv(self.results_dir / "BDD_breaks.csv", index=False)
         return dict(zip([t.stem for t in txts], labels))
 
     # ------------------------------------------------------------------ step table
@@ -500,9 +542,12 @@ class AudioPipeline:
                 logging.exception(f"Failed step {n}")
                 sys.exit(1)
         import yaml
+        from . import shard
         config_path = self.results_dir / "used_config.yaml"
-        with open(config_path, "w", encoding="utf-8") as f:
-            yaml.dump(self.cfg, f, default_flow_style=False, allow_unicode=True)
+        with shard.agreed(only_rank=0) as sec:
+            if sec.mine:
+                with open(config_path, "w", encoding="utf-8") as f:
+                    yaml.dump(self.cfg, f, default_flow_style=False, allow_unicode=True)
         logging.info(f"Config saved to {config_path}")
 
 

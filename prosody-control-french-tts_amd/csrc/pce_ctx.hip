@@ -119,22 +119,10 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->generic_median = getenv("PCE_ALIGN_GENERIC_MEDIAN") != nullptr;
     c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
     c->en_cpb = getenv("PCE_EN_CPB") ? atoi(getenv("PCE_EN_CPB")) : 0;
-    c->en_iters = (getenv("PCE_EN_ITERS") && atoi(getenv("PCE_EN_ITERS")) == 16) ? 16 : 8;
     c->gemm_skinny = !(getenv("PCE_GEMM_SKINNY") && atoi(getenv("PCE_GEMM_SKINNY")) == 0);
-    c->attn1 = getenv("PCE_ATTN1") ? atoi(getenv("PCE_ATTN1")) : 2;    // measured: 115.8 (wave per head) vs 119.6 us (workgroup per head) per launch
     // default: fp16 operands, the reference's own arithmetic (and the closer of the two to the fp32 restatement: DESIGN.md section 4)
     c->whisper_ops = (getenv("PCE_WHISPER_OPERANDS") && !strcmp(getenv("PCE_WHISPER_OPERANDS"), "bf16")) ? 0 : 1;
-    c->attn_mode = getenv("PCE_ATTN") ? atoi(getenv("PCE_ATTN")) : 1;
-    c->gemm_sm = getenv("PCE_GEMM_SM") ? atoi(getenv("PCE_GEMM_SM")) : 0;
-    c->gemm_sn = getenv("PCE_GEMM_SN") ? atoi(getenv("PCE_GEMM_SN")) : 0;
-    c->gemm_wide = getenv("PCE_GEMM_WIDE") ? atoi(getenv("PCE_GEMM_WIDE")) : -1;
-    c->gemm_trace = getenv("PCE_GEMM_TRACE") != nullptr;
-    c->dbg_pitch_lds_fft = getenv("PCE_PITCH_LDS_FFT") != nullptr;
     c->pitch_refine_praat = getenv("PCE_PITCH_REFINE") && !strcmp(getenv("PCE_PITCH_REFINE"), "praat");
-    c->dbg_pitch_tabs = getenv("PCE_PITCH_TABS") ? atoi(getenv("PCE_PITCH_TABS")) : -1;
-    c->dbg_pitch = getenv("PCE_DBG") ? atoi(getenv("PCE_DBG")) : 0;
-    c->refine_blocks_per_cu = getenv("PCE_K2_BPC") ? atoi(getenv("PCE_K2_BPC")) : 24;
-    if (c->refine_blocks_per_cu < 1) c->refine_blocks_per_cu = 24;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int si = 0; si < pce_ctx::SIDE_COUNT; si++) {

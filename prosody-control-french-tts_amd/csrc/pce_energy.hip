@@ -15,7 +15,8 @@
 namespace {
 
 constexpr int EN_THREADS = 256;
-// loads per lane in flight = chunk size / 4 KiB: 8 (32 KiB chunks) by default, 16 (64 KiB) with PCE_EN_ITERS=16 at pce_create
+// loads per lane in flight = chunk size / 4 KiB: EN_LOADS = 8 (32 KiB chunks; 16 measured no better)
+constexpr int EN_LOADS = 8;
 static inline int64_t en_chunk(int iters) { return (int64_t)EN_THREADS * 8 * iters; }
 
 struct EnWork { int64_t g0, g1; int32_t slice; int32_t pad; };
@@ -186,7 +187,7 @@ int pce_energy_plan(pce_ctx *c, const pce_slice *slices, int32_t n, DevBuf &work
         int64_t b = s.begin < 0 ? 0 : s.begin, e = s.end > len ? len : s.end;
         if (e <= b) continue;
         const int64_t g0 = c->clip_off[s.clip] + b, g1 = c->clip_off[s.clip] + e;
-        const int64_t EN_CHUNK = en_chunk(c->en_iters);
+        const int64_t EN_CHUNK = en_chunk(EN_LOADS);
         for (int64_t p = g0; p < g1;) {
             int64_t q = ((p / EN_CHUNK) + 1) * EN_CHUNK;
             if (q > g1) q = g1;
@@ -221,8 +222,7 @@ int pce_energy_launch(pce_ctx *c, int32_t n, int32_t loud_thr, int64_t n_work, D
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(EN_THREADS), 0, st, c->d_pcm, work_buf.as<EnWork>(), (int)n_work, cpb, (int)loud_thr, out_buf.as<EnAcc>());
         };
-        if (c->en_iters == 16) { if (nt) launch(k_energy<16, true>); else launch(k_energy<16, false>); }
-        else { if (nt) launch(k_energy<8, true>); else launch(k_energy<8, false>); }
+        if (nt) launch(k_energy<EN_LOADS, true>); else launch(k_energy<EN_LOADS, false>);
         PCE_HIP(c, hipGetLastError());
     }
     return PCE_OK;

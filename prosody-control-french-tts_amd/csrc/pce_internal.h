@@ -51,17 +51,13 @@ struct pce_ctx {
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; } side[SIDE_COUNT];
     bool no_side = false;                // PCE_NO_AUX at pce_create: everything on `stream`
     bool generic_median = false;         // PCE_ALIGN_GENERIC_MEDIAN at pce_create: the insertion-sort median filter for every width
-    // debugging / tuning knobs, read once at pce_create (never in a launch path)
     bool pitch_refine_praat = false;     // PCE_PITCH_REFINE=praat at pce_create: the candidate refinement replays NUMminimize_brent's own iterates (round 1 / 2 behaviour)
-    bool dbg_pitch_lds_fft = false; int dbg_pitch_tabs = -1, dbg_pitch = 0, refine_blocks_per_cu = 24;
-    int attn1 = 2;                       // PCE_ATTN1 at pce_create (default 2): 0 = incremental decoding steps keep the MFMA attention kernel (one live query per tile), 1 = k_cross_attn1
-                                         // (a workgroup per clip and head), 2 = k_cross_attn1w (a workgroup per clip, a wave per head)
-    bool attn1w_attr = false;
-    int attn_mode = 1;                   // PCE_ATTN at pce_create: 1 = k_attention_lean (default), 2 = its exact path only, 0 = k_attention (round 1)
-    int gemm_sm = 0, gemm_sn = 0, gemm_wide = -1; bool gemm_trace = false;   // PCE_GEMM_SM / _SN / _WIDE / _TRACE: rasterisation and tile-shape overrides, phase stamps (tiled kernels)
-    bool gemm_flat_attr[4] = {false, false, false, false};   // k_gemm_flat<EPI>: dynamic-LDS opt-in done on this context's device
+    // dynamic-LDS opt-ins (hipFuncSetAttribute) done on this context's device, per operand-type build: the implementation file is compiled
+    // twice, so every kernel below exists as two distinct functions
+    bool attn1w_attr[2] = {false, false};
+    bool gemm_flat_attr[2][4] = {{false, false, false, false}, {false, false, false, false}};   // k_gemm_flat<EPI>
     bool gemm_few_rows = false;          // set by the incremental decoding step around its launches: k_gemm_skinny is eligible
-    bool gemm_skinny = true, gemm_skinny_attr[4] = {false, false, false, false};   // PCE_GEMM_SKINNY=0 at pce_create: few-row launches stay on the 128 x 128 kernel
+    bool gemm_skinny = true, gemm_skinny_attr[2][4] = {{false, false, false, false}, {false, false, false, false}};   // PCE_GEMM_SKINNY=0 at pce_create: few-row launches stay on the 128 x 128 kernel
     bool gemm_flat = true;               // PCE_GEMM_FLAT=0 at pce_create: the encoder's projections stay on the 128 x 128 / 128 x 256 tile kernels
     bool stft_two_fft = false;           // PCE_STFT_TWO_FFT at pce_create: traffic-minimal STFT-dB (the FFT runs twice)
     std::string err;
@@ -77,7 +73,6 @@ struct pce_ctx {
 
     // energy
     int en_cpb = 0;                 // PCE_EN_CPB: chunks per k_energy workgroup (0 = by batch size)
-    int en_iters = 8;               // PCE_EN_ITERS at pce_create (8 or 16): 16-byte loads per lane in flight = chunk size / 4 KiB
     DevBuf en_work, en_out;
     SliceCache en_cache;
     int64_t en_n_work = 0;
@@ -128,7 +123,7 @@ struct pce_ctx {
     // whisper / BERT state, opaque (pce_whisper_impl.inc): one slot per operand-type build (0: bf16, 1: fp16); whisper_ops selects the build the
     // entry points of include/pce.h forward to (pce_whisper_set_operands, or PCE_WHISPER_OPERANDS=fp16 at pce_create)
     void *whisper_slot[2] = {nullptr, nullptr};
-    int whisper_ops = 0;
+    int whisper_ops = 1;                 // (pce_create: fp16 unless PCE_WHISPER_OPERANDS=bf16)
 
     // asynchronous statistics fetch (pce_stats_enqueue / pce_stats_wait)
     struct StatSlot {

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
     const long long *acc_sum, const int *acc_hi, const int *acc_lo, size_t acc_stride,
     double *__restrict__ cand /* [frames][32]: 16 freq, 16 strength */, int *__restrict__ ncand, double *__restrict__ intensity,
     double *__restrict__ rr_out /* [frames][rr_half]: r[0..bix] */, RefineItem *__restrict__ items, unsigned int *__restrict__ item_count,
-    unsigned int list_cap, int dbg, const double *__restrict__ blob /* register paths: lane-ordered twiddles, twN, window, windowR */)
+    unsigned int list_cap, const double *__restrict__ blob /* register paths: lane-ordered twiddles, twN, window, windowR */)
 {
     // the LUFS chain runs beside this kernel on a side stream (few waves, long dependent fp64 chains): with this kernel's
     // waves at a higher issue priority it only takes the slots they leave (2.94 -> 2.88 ms per step; raising the
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
         } else {
         wave_sync();
         // forward transform of the packed frame
-        double2 *Z = (dbg & 1) ? bufA : fft_wave(bufA, bufB, M, twM, lane);
+        double2 *Z = fft_wave(bufA, bufB, M, twM, lane);
         double2 *W = (Z == bufA) ? bufB : bufA;
         // power spectrum of the real frame, re-tangled for the second (inverse) transform
         for (int k = lane; k <= (M >> 1); k += 64) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
             if (k != 0 && k != M - k) W[ZP(M - k)] = make_double2(e + d * sn, -(d * c));
         }
         wave_sync();
-        double2 *Y = (dbg & 1) ? W : fft_wave(W, Z, M, twM, lane);
+        double2 *Y = fft_wave(W, Z, M, twM, lane);
         rr = reinterpret_cast<double *>((Y == bufA) ? bufB : bufA);       // the free buffer holds r[-bix..bix]
         const double ac0 = Y[0].x;
         for (int k = lane + 1; k <= P.bix; k += 64) {
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pitch_frames(
             }
             if (mine) n = ng;
         }
-        if (n > 1 && !(dbg & 2)) {
+        if (n > 1) {
             // hand r[-bix..bix] and the candidate lags to k_pitch_refine
             // r is even: only r[0..bix] travels (half the bytes written here and read by k_pitch_refine)
             double *ro = rr_out + fidx * (int64_t)P.rr_half;
@@ -1437,6 +1437,14 @@ int pce_pitch_plan(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slice
     return PCE_OK;
 }
 
+int pce_pitch_set_refine(pce_ctx *c, int32_t mode)
+{
+    if (!c || (mode != PCE_REFINE_SEEDED && mode != PCE_REFINE_PRAAT)) return PCE_E_INVALID;
+    const bool praat = mode == PCE_REFINE_PRAAT;
+    if (c->pitch_refine_praat != praat) { c->pitch_refine_praat = praat; c->pi_cache.drop(); c->pi_params_valid = false; }
+    return PCE_OK;
+}
+
 int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices, int32_t n)
 {
     if (!c || !p || (!slices && n > 0) || n < 0) return PCE_E_INVALID;
@@ -1471,12 +1479,11 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             if (lds_wave > 160 * 1024) return pce_fail(c, PCE_E_LIMIT, "analysis window of %d samples does not fit LDS", P.nw);
             // register-resident transforms where N allows it and r[-bix..bix] fits the exchange region
             // (tables stay in global memory: staging them in LDS per workgroup measured slower than L1 hits)
-            P.mode = c->dbg_pitch_lds_fft ? 0
-                     : (nfft == 1024 && P.rr_len <= R_WAVE_F64) ? 1
+            P.mode = (nfft == 1024 && P.rr_len <= R_WAVE_F64) ? 1
                      : (nfft == 512 && P.rr_len <= R_WAVE_F64 / 2) ? 2
                      : (nfft == 2048 && P.rr_len <= R3_WAVE_F64) ? 3 : 0;
             P.fpb = P.mode == 2 ? 2 * PI_FPB : PI_FPB;
-            P.tabs = P.mode == 3 ? 0 : c->dbg_pitch_tabs >= 0 ? c->dbg_pitch_tabs != 0 : P.mode == 2;   // MODE 3: 75 KB of exchange images leave no room
+            P.tabs = P.mode == 2;   // MODE 3: 75 KB of exchange images leave no room
             std::vector<double> tw((size_t)(Mc + Mc + 1) * 2);
             for (int m = 0; m < Mc; m++) { tw[2 * (size_t)m] = std::cos(2.0 * PI_D * m / Mc); tw[2 * (size_t)m + 1] = -std::sin(2.0 * PI_D * m / Mc); }
             for (int k = 0; k <= Mc; k++) { tw[2 * (size_t)(Mc + k)] = std::cos(2.0 * PI_D * k / nfft); tw[2 * (size_t)(Mc + k) + 1] = -std::sin(2.0 * PI_D * k / nfft); }
@@ -1608,12 +1615,10 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                                        c->pi_window.as<double>(), c->pi_windowR.as<double>(), c->pi_tw.as<double2>(),
                                        c->pi_tw.as<double2>() + (P.nfft >> 1), a_sum, a_hi, a_lo, stride,
                                        c->pi_cand.as<double>(), ncand, intensity, c->pi_rr.as<double>(), items, item_count, list_cap,
-                                       c->dbg_pitch, c->pi_blob.as<double>());
+                                       c->pi_blob.as<double>());
                 };
-                if (P.mode == 1 && P.tabs) launch(k_pitch_frames<4, 1, true>);
-                else if (P.mode == 1) launch(k_pitch_frames<4, 1, false>);
-                else if (P.mode == 2 && P.tabs) launch(k_pitch_frames<4, 2, true>);
-                else if (P.mode == 2) launch(k_pitch_frames<4, 2, false>);
+                if (P.mode == 1) launch(k_pitch_frames<4, 1, false>);
+                else if (P.mode == 2) launch(k_pitch_frames<4, 2, true>);
                 else if (P.mode == 3) launch(k_pitch_frames<4, 3, false>);
                 else if (wpb == 4) launch(k_pitch_frames<4, 0, false>);
                 else if (wpb == 2) launch(k_pitch_frames<2, 0, false>);
@@ -1628,7 +1633,7 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
                 // fused kernel against 0.95 + 0.98 -- a wavefront's two frames hold ~11 candidates, so its eight lane groups run two rounds of
                 // 3-4 dependent evaluations at 70 % occupancy of the lanes, serialised behind its own transforms, where this kernel packs
                 // eight candidates of any frames into every wavefront.
-                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * (unsigned)c->refine_blocks_per_cu * 4u;
+                const unsigned blocks = (unsigned)(c->cu_count > 0 ? c->cu_count : 256) * 96u;
                 hipLaunchKernelGGL(k_pitch_refine<8>, dim3(blocks), dim3(64), 0, c->stream, P, c->pi_rr.as<double>(), items, item_count,
                                    list_cap, c->pi_cand.as<double>());
             }

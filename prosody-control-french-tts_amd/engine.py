@@ -106,7 +106,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_upload_pcm_s16", "pce_bind_pcm_s16_device", "pce_num_clips",
            "pce_energy_run", "pce_energy_fetch", "pce_lufs_set_meter_rate", "pce_lufs_run", "pce_lufs_fetch",
            "pce_frame_energy_run", "pce_frame_energy_shape", "pce_frame_energy_fetch", "pce_pyin_run", "pce_pyin_shape", "pce_pyin_fetch",
-           "pce_pitch_plan", "pce_pitch_run", "pce_pitch_fetch",
+           "pce_pitch_plan", "pce_pitch_run", "pce_pitch_set_refine", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
            "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
@@ -133,6 +133,7 @@ def load_library() -> C.CDLL:
     lib.pce_energy_run.argtypes = [vp, vp, i32, i32]
     lib.pce_energy_fetch.argtypes = [vp, vp]
     lib.pce_lufs_set_meter_rate.argtypes = [vp, i32]
+    lib.pce_pitch_set_refine.argtypes = [vp, i32]
     lib.pce_lufs_run.argtypes = [vp, vp, i32]
     lib.pce_frame_energy_run.argtypes = [vp, i32, i32, i32]
     lib.pce_pyin_run.argtypes = [vp, vp, vp, i64]
@@ -290,6 +291,12 @@ class ProsodyEngine:
         """``pyln.Meter(rate)`` of the following ``lufs`` calls (0: the batch's own rate)."""
         self._check(self._lib.pce_lufs_set_meter_rate(self._ctx, int(rate)))
 
+    def pitch_set_refine(self, mode: str = "seeded"):
+        """How candidate maxima are refined (``pce_pitch_set_refine``): ``"seeded"`` (default: parabolic search seeded with the samples
+        around the peak, Praat's own iterates only where the two could differ) or ``"praat"`` (NUMminimize_brent's iterates for every
+        candidate).  Additive config key of ``AudioPipeline``: ``pitch_refine``."""
+        self._check(self._lib.pce_pitch_set_refine(self._ctx, {"seeded": 0, "praat": 1}[str(mode).lower()]))
+
     def lufs_run(self, slices):
         s = self._slices(slices); self._lu_n = len(s)
         self._check(self._lib.pce_lufs_run(self._ctx, s.ctypes.data, len(s)))
@@ -403,7 +410,7 @@ class ProsodyEngine:
 
     # ---------------------------------------------------------------- operand type of the Whisper / BERT products
     def whisper_set_operands(self, kind: str):
-        """``"bf16"`` (default) or ``"fp16"`` (the reference's own arithmetic: openai-whisper's fp16=True).  The two builds keep
+        """``"fp16"`` (default: the reference's own arithmetic, openai-whisper's fp16=True) or ``"bf16"``.  The two builds keep
         separate state: select BEFORE loading weights / running the log-mel, and load again after switching."""
         code = {"bf16": 0, "fp16": 1}[str(kind).lower()]
         self._check(self._lib.pce_whisper_set_operands(self._ctx, code))
@@ -459,7 +466,7 @@ class ProsodyEngine:
 
     def selftest_attention(self, q, k, v, causal: bool = False, mode: int = 0):
         """softmax(q k^T / 8) v per (clip, head) on the attention kernel; q [clips][q_len][heads*64], k / v [clips][k_len][heads*64] float
-        arrays (rounded to bf16 here).  mode 0: as the engine runs it, 1: exact path only, 2: the round-1 kernel.  Returns (out float32 decoded
+        arrays (rounded to bf16 here).  mode 0: as the engine runs it, 1: exact path only.  Returns (out float32 decoded
         from bf16, number of workgroups that fell back to the exact path)."""
         import torch
         tq, tk, tv = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._op_dtype()).contiguous() for x in (q, k, v))

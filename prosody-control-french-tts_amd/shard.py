@@ -38,21 +38,58 @@ def rank_world():
     return 0, 1
 
 
-def barrier():
-    """No-op without a process group."""
+class PeerFailure(RuntimeError):
+    """Another rank failed in the section all ranks have just left (or flagged its block of an exchange as failed): this rank
+    stops the same step, so that the next collective every rank enters is the same one."""
+
+
+def barrier(ok: bool = True) -> bool:
+    """Barrier that carries a status: every rank passes whether its rank-local work succeeded and every rank learns whether ALL
+    did (one 1-element MIN all-reduce: what ``dist.barrier`` costs, control plane only).  No-op (-> ``ok``) without a process
+    group.  A rank must reach this call whether or not its local work raised: see :class:`agreed`."""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(ok)
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
 
 
-def allgather_records(local: np.ndarray, counts=None, device=None) -> np.ndarray:
+class agreed:
+    """``with shard.agreed(): <rank-local work, no collective inside>``: every rank leaves the block through the same status
+    barrier whether its work raised or not; a local exception propagates on its rank and every other rank raises
+    :class:`PeerFailure`, so a failure on one rank fails the step on all of them together instead of leaving the others inside the
+    next collective.  ``only_rank``: the body runs on that rank alone (``if a.mine:``), the others just wait for it."""
+
+    def __init__(self, only_rank=None):
+        self.rank = rank_world()[0]
+        self.mine = only_rank is None or self.rank == only_rank
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        failed = exc_type is not None and not (exc_type is SystemExit and not getattr(exc, "code", 0))
+        all_ok = barrier(not failed)
+        if exc_type is None and not all_ok:
+            raise PeerFailure("another rank failed in this section")
+        return False
+
+
+def allgather_records(local: np.ndarray, counts=None, device=None, failed: bool = False) -> np.ndarray:
     """All-gather ragged per-rank record blocks ``[n_local, width]`` (float64) into ``[n_total, width]`` in rank order
     with ONE collective (``all_gather_into_tensor``; RCCL over xGMI when the backend is "nccl").
 
     ``counts``: rows every rank contributes, known to all ranks without talking -- ``shard_range`` sizes for
     per-utterance records, TextGrid-derived syntagme counts for the tagger.  Blocks are padded to ``max(counts)``.
     Without ``counts`` the block sizes have to be agreed on first (one extra scalar MAX all-reduce; the row count then
-    rides in a header row): callers on the hot path always pass ``counts``."""
+    rides in a header row): callers on the hot path always pass ``counts``.
+
+    ``failed``: this rank could not produce its block (its measurements raised).  It still takes part in the ONE collective -- the
+    block's trailing status row says so -- and every rank, this one included, raises :class:`PeerFailure` after it: a rank-local
+    failure never leaves the other ranks waiting inside the exchange, and costs no extra collective."""
     import torch
     import torch.distributed as dist
 
@@ -60,6 +97,8 @@ def allgather_records(local: np.ndarray, counts=None, device=None) -> np.ndarray
     if local.ndim != 2:
         raise ValueError("records must be [n, width]")
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if failed:
+            raise PeerFailure("rank 0 could not produce its records")
         if counts is not None and int(counts[0]) != local.shape[0]:
             raise ValueError(f"rank 0 holds {local.shape[0]} records, counts says {counts[0]}")
         return local.copy()
@@ -74,17 +113,25 @@ def allgather_records(local: np.ndarray, counts=None, device=None) -> np.ndarray
         cap, header = int(cap.item()), 1
     else:
         counts = [int(c) for c in counts]
-        if len(counts) != world or counts[rank] != local.shape[0]:
-            raise ValueError(f"rank {rank} holds {local.shape[0]} records, counts = {counts}")
+        if len(counts) != world:
+            raise ValueError(f"counts = {counts} for {world} ranks")          # (the same on every rank: nobody enters the collective)
+        if counts[rank] != local.shape[0]:
+            failed = True                                                    # a rank-local mismatch must not leave the others waiting
         cap = max(counts) if counts else 0
-    block = torch.zeros((cap + header, width), dtype=torch.float64, device=device)
+    if failed:
+        local = np.zeros((0, width))
+    block = torch.zeros((cap + header + 1, width), dtype=torch.float64, device=device)
     if header:
         block[0, 0] = float(local.shape[0])
+    block[cap + header, 0] = 1.0 if failed else 0.0                          # trailing status row
     if local.shape[0]:
         block[header:header + local.shape[0]] = torch.from_numpy(local).to(device)
-    out = torch.empty((world * (cap + header), width), dtype=torch.float64, device=device)
+    out = torch.empty((world * (cap + header + 1), width), dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(out, block)
-    out = out.cpu().numpy().reshape(world, cap + header, width)
+    out = out.cpu().numpy().reshape(world, cap + header + 1, width)
+    bad = [r for r in range(world) if out[r, cap + header, 0] != 0.0]
+    if bad:
+        raise PeerFailure(f"rank(s) {bad} could not produce their records")
     if header:
         counts = [int(out[r, 0, 0]) for r in range(world)]
     parts = [out[r, header:header + counts[r]] for r in range(world)]

@@ -377,15 +377,27 @@ class SsmlTagger:
         lo, hi = spans[rank]
         mine = segments[lo:hi]
         res = TaggerResult()
-        local = self.segment_statistics(mine, src)
-        meas = self.syntagme_measurements(mine, src)
-        index = {s.name: i for i, s in enumerate(segments)}
-        rec = np.zeros((len(local) + len(meas), RECORD_WIDTH), dtype=np.float64)
-        for k, st in enumerate(local):
-            rec[k, 1:1 + len(SEGMENT_RECORD)] = [st[f] for f in SEGMENT_RECORD]
-        for k, m in enumerate(meas, start=len(local)):
-            rec[k, 0] = 1.0
-            rec[k, 1:1 + len(SYNTAGME_RECORD)] = [index[m["segment"]]] + [m[f] for f in SYNTAGME_RECORD[1:]]
+        # the rank-local part may raise (an undecodable file, a slice Praat refuses, a device error): the rank still enters the ONE
+        # collective, with its block flagged as failed, so that every rank leaves the step together (``shard.allgather_records``)
+        local_error = None
+        try:
+            local = self.segment_statistics(mine, src)
+            meas = self.syntagme_measurements(mine, src)
+            index = {s.name: i for i, s in enumerate(segments)}
+            rec = np.zeros((len(local) + len(meas), RECORD_WIDTH), dtype=np.float64)
+            for k, st in enumerate(local):
+                rec[k, 1:1 + len(SEGMENT_RECORD)] = [st[f] for f in SEGMENT_RECORD]
+            for k, m in enumerate(meas, start=len(local)):
+                rec[k, 0] = 1.0
+                rec[k, 1:1 + len(SYNTAGME_RECORD)] = [index[m["segment"]]] + [m[f] for f in SYNTAGME_RECORD[1:]]
+        except Exception as e:                                               # noqa: BLE001
+            local_error = e
+        if local_error is not None:
+            try:
+                allgather(np.zeros((0, RECORD_WIDTH)), counts, failed=True)
+            except Exception:                                                # noqa: BLE001  (PeerFailure: what it is for)
+                pass
+            raise local_error
         allrec = allgather(rec, counts)
         seg_rec, syn_rec = allrec[allrec[:, 0] == 0.0], allrec[allrec[:, 0] == 1.0]
         texts = [(i, syn["words"]) for i, syns in enumerate(syn_of) for syn in syns]

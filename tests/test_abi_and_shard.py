@@ -23,6 +23,12 @@ def test_build_and_exports_match_header():
     assert declared == set(E.EXPORTS), declared ^ set(E.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
+    # ... and nothing else: the dynamic symbol table of libpce.so is exactly the header (no per-operand-type dispatch targets, no C++
+    # internals, no template instantiations: -fvisibility=hidden + csrc/libpce.map)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", E.native_library_path()], stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    exported = {ln.split()[-1] for ln in nm if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
     lib.pce_api_version.restype = ctypes.c_int
     assert lib.pce_api_version() == 1
     lib.pce_kernel_name.restype = ctypes.c_char_p
@@ -79,10 +85,32 @@ got = shard.allgather_records(full[lo:hi], counts)          # the hot-path form:
 assert got.shape == (n, 7) and np.array_equal(got, full), got
 got = shard.allgather_records(full[lo:hi])                  # sizes unknown: header row + one scalar all-reduce
 assert got.shape == (n, 7) and np.array_equal(got, full), got
-try:
+try:                                                        # a block that contradicts counts: flagged INSIDE the collective, every rank raises
     shard.allgather_records(full[lo:hi], [c + 1 for c in counts]); raise SystemExit("wrong counts accepted")
-except ValueError:
+except shard.PeerFailure:
     pass
+# a rank whose local work failed still takes part in the ONE collective and every rank learns it (no rank is left waiting)
+try:
+    shard.allgather_records(full[lo:hi] if rank == 0 else np.zeros((0, 7)), counts, failed=rank == 1); raise SystemExit("failure not propagated")
+except shard.PeerFailure as e:
+    assert "[1]" in str(e), str(e)
+assert np.array_equal(shard.allgather_records(full[lo:hi], counts), full)      # ... and the group is still in step afterwards
+# status barrier / agreed sections: a local exception propagates on its rank, the others raise PeerFailure, nobody hangs
+assert shard.barrier(True) is True and shard.barrier(rank == 0) is False
+try:
+    with shard.agreed():
+        if rank == 1:
+            raise KeyError("local")
+    raise SystemExit("rank %d left a failed section normally" % rank)
+except KeyError:
+    assert rank == 1
+except shard.PeerFailure:
+    assert rank == 0
+ran = []
+with shard.agreed(only_rank=0) as sec:
+    if sec.mine:
+        ran.append(rank)
+assert ran == ([0] if rank == 0 else [])
 empty = shard.allgather_records(np.zeros((0 if rank else 2, 3)))
 assert empty.shape == (2, 3)
 dist.barrier(); dist.destroy_process_group()

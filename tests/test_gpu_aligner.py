@@ -163,9 +163,38 @@ def test_device_resident_decode_loop_equals_the_host_driven_loop(engine, model_d
     ended = [p + [rules["eot"]] for p in prompts]
     toks, lps, _ = engine.whisper_decode_loop(ended, begins, rules["eot"], rules["timestamp_begin"], mask, 12, rules["max_initial_timestamp_index"])
     assert toks.shape[1] == 1 and (toks == rules["eot"]).all() and (lps == 0).all()
-    # a prompt that leaves no room for max_new tokens is refused, not truncated
-    with pytest.raises(Exception):
-        engine.whisper_decode_loop(prompts, begins, rules["eot"], rules["timestamp_begin"], mask, tdims["n_text_ctx"], rules["max_initial_timestamp_index"])
+
+
+def test_decode_loop_stops_a_sequence_at_the_text_context(engine, model_dir):
+    """A prompt of n_text_ctx // 2 + 3 tokens (``condition_on_previous_text``: up to 227 of 448 at full size, 67 of 128 here) plus
+    sample_len = n_text_ctx // 2 sampled ones exceeds the text context.  openai-whisper's loop breaks when ``tokens.shape[-1] > n_ctx``
+    (decoding.py, DecodingTask._main_loop) and keeps what was sampled; the device loop does the same PER SEQUENCE (the other clips of
+    the batch go on) instead of refusing the window, also in a temperature-fallback round where the clip with the longest prompt is
+    already accepted (inactive: prompt + end-of-text).  End-of-text is suppressed here so that every sequence runs into a limit."""
+    clips = [synth.synth_clip(i, seconds=3.0) for i in range(3)]
+    model, tk, tdims, dec = _encode_clips(engine, model_dir, clips)
+    n_ctx = tdims["n_text_ctx"]
+    rules = tk.decoding_rules()
+    rules = dict(rules, suppress_tokens=sorted(set(rules["suppress_tokens"]) | {rules["eot"]}))
+    V = tdims["n_vocab"]
+    sot = list(tk.sot_sequence())
+    prev = (tk.encode(" bonjour le monde") * 40)[: n_ctx // 2 - 1]
+    long_prompt = [tk.sot_prev] + prev + sot
+    assert len(long_prompt) == n_ctx // 2 + len(sot)
+    prompts = [long_prompt, sot, [tk.sot_prev] + prev[:5] + sot]
+    begins = [len(p) for p in prompts]
+    sample_len = n_ctx // 2
+    assert begins[0] + sample_len > n_ctx
+    for active in (None, [False, True, True]):
+        host = DEC.decode_batch(engine, V, prompts, begins, rules, sample_len, active=active, device_loop=False, n_text_ctx=n_ctx)
+        dev = DEC.decode_batch(engine, V, prompts, begins, rules, sample_len, active=active, device_loop=True, n_text_ctx=n_ctx)
+        assert dev[0] == host[0], active
+        assert np.allclose(dev[2], host[2], atol=2e-2)
+        if active is None:
+            assert len(dev[0][0]) == n_ctx + 1 - begins[0]               # the forward pass over the full context still yields its token
+        else:
+            assert dev[0][0] == []
+        assert len(dev[0][1]) == sample_len and len(dev[0][2]) == sample_len      # the clips with room were not cut short
 
 
 # ----------------------------------------------------------------------------------------------------- transcription flow

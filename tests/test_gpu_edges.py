@@ -291,3 +291,57 @@ def test_c4_shard_size_batch_equals_its_sub_batches():
         assert whole[j] == b"".join(pt[j] for pt in parts), j
     for j in (4, 5, 6):
         assert whole[j] == [x for pt in parts for x in pt[j]], j
+
+
+@pytest.mark.gpu
+def test_environment_switches_of_pce_create(engine, monkeypatch):
+    """Every environment variable pce_create still reads selects code a test runs (PCE_NO_AUX, PCE_STFT_TWO_FFT, PCE_EN_CPB,
+    PCE_ALIGN_GENERIC_MEDIAN have their own tests); here the remaining four:
+    PCE_WHISPER_OPERANDS=bf16 / PCE_PITCH_REFINE=praat -> the context's defaults for what pce_whisper_set_operands / pce_pitch_set_refine
+    set; PCE_GEMM_FLAT=0 -> the encoder's projections on the 128 x 128 / 128 x 256 tile kernels instead of the persistent 256 x 256 one
+    (same products: outputs agree to the rounding of a 16-bit store); PCE_GEMM_SKINNY=0 -> the few-row GEMMs of an incremental decoding
+    step on the tiled kernel (bit-identical sums: the same tokens and log-probabilities from the device-resident loop)."""
+    from prosody_control_french_tts_amd import synth, whisper_weights as WW
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    from prosody_control_french_tts_amd.Aligners.tokenizer import WhisperTokenizer
+    monkeypatch.setenv("PCE_WHISPER_OPERANDS", "bf16"); monkeypatch.setenv("PCE_PITCH_REFINE", "praat")
+    clips = [synth.synth_clip(i, seconds=3.0) for i in range(2)]
+    p = pkg.PitchParams.praat(150.0, 600.0)
+    with pkg.ProsodyEngine(0) as eng:
+        assert eng.whisper_operands == "bf16"
+        eng.upload(clips, 16000)
+        praat = eng.pitch(eng.whole_clip_slices(), p, want_f0=True)["f0"]
+    monkeypatch.delenv("PCE_WHISPER_OPERANDS"); monkeypatch.delenv("PCE_PITCH_REFINE")
+    assert engine.whisper_operands == "fp16"
+    engine.upload(clips, 16000)
+    engine.pitch_set_refine("praat")
+    try:
+        assert engine.pitch(engine.whole_clip_slices(), p, want_f0=True)["f0"].tobytes() == praat.tobytes()      # the env default IS the API's mode
+    finally:
+        engine.pitch_set_refine("seeded")
+    # ---- the two GEMM routing switches, on a model wide enough for the persistent kernel (n_state % 256 == 0, M = 2 x 1500 rows)
+    edims = dict(n_mels=80, n_ctx=1500, n_state=256, n_head=4, n_layer=2)
+    tk = WhisperTokenizer.toy([b" b", b"on", b" bon", b"jo", b"ur"], language="fr")
+    tdims = dict(n_vocab=tk.n_vocab, n_text_ctx=64, n_state=256, n_head=4, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=3), WW.greedy_test_decoder_weights(tdims, seed=4)
+    rules = tk.decoding_rules()
+    prompts = [list(tk.sot_sequence())] * 2
+
+    def run(eng):
+        eng.upload(clips, 16000); eng.logmel_run(80)
+        eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
+        enc = [eng.whisper_encode_fetch(i) for i in range(2)]
+        eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+        toks, lps, sums = DEC.decode_batch(eng, tdims["n_vocab"], prompts, [len(q) for q in prompts], rules, 12)
+        return enc, toks, lps
+
+    base = run(engine)
+    for var in ("PCE_GEMM_FLAT", "PCE_GEMM_SKINNY"):
+        monkeypatch.setenv(var, "0")
+        with pkg.ProsodyEngine(0) as other:
+            got = run(other)
+        monkeypatch.delenv(var)
+        for a, b in zip(got[0], base[0]):
+            assert np.isfinite(a).all() and np.linalg.norm(a - b) / np.linalg.norm(b) <= 2e-3, var
+        if var == "PCE_GEMM_SKINNY":
+            assert got[1] == base[1] and all(np.array_equal(x, y) for x, y in zip(got[2], base[2]))

@@ -201,3 +201,40 @@ def test_lufs_ebu_tech_3341_cases_on_the_gpu(engine, rate):
     for (x, want), v, code in zip(sigs, vals, st):
         assert code == 0 and abs(v - want) <= 0.1, (rate, v, want)
         assert abs(v - O.lufs_c(x.astype(np.float64), rate)) <= 1e-6
+
+
+def test_refine_modes_give_the_same_f0_tracks(engine, synth16k):
+    """``pce_pitch_set_refine``: the default candidate search (seeded parabolic interpolation, Praat's iterates only where the two could
+    differ) against NUMminimize_brent's own iterates for every candidate (PCE_REFINE_PRAAT), on real speech (C1, the 44.1 kHz demo
+    excerpts) and the synthetic set.  Compared are the FULL F0 tracks after the path finder -- which candidate wins every frame, not
+    only the candidates' values: the same voiced / unvoiced decision in every frame, F0 within 1e-6 relative, strengths within 1e-6,
+    the medians the tagger consumes within 1e-6 relative; and the praat mode itself against the oracle."""
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    c1 = np.load(os.path.join(g, "c1_segment_ph9_16k.npz"))["pcm"]
+    z = np.load(os.path.join(g, "demo_excerpts.npz"))
+    sets = [([c1] + list(synth16k[:4]), 16000), ([z[k] for k in sorted(z.files) if k != "rate"][:5], int(z["rate"]))]
+    try:
+        for clips, rate in sets:
+            engine.upload(clips, rate)
+            sl = engine.whole_clip_slices()
+            tracks = {}
+            for mode in ("seeded", "praat"):
+                engine.pitch_set_refine(mode)
+                tracks[mode] = engine.pitch(sl, E.PitchParams.praat(150.0, 600.0), want_f0=True, want_strength=True)
+            a, b = tracks["seeded"], tracks["praat"]
+            assert np.array_equal(a["frame_offsets"], b["frame_offsets"])
+            va, vb = a["f0"] > 0, b["f0"] > 0
+            assert np.array_equal(va, vb) and va.sum() > 200                       # the path finder took the same decisions
+            assert np.max(np.abs(a["f0"][va] - b["f0"][va]) / b["f0"][va]) <= 1e-6
+            assert np.max(np.abs(a["strength"][va] - b["strength"][va])) <= 1e-6
+            for sa, sb in zip(a["summary"], b["summary"]):
+                assert sa["n_voiced"] == sb["n_voiced"] and abs(sa["median_f0"] - sb["median_f0"]) <= 1e-6 * max(sb["median_f0"], 1.0)
+            want = O.pitch_ac(clips[0].astype(np.float64) / 32768.0, 1.0 / rate, 0.5 / rate, O.praat_params(150.0, 600.0))["f0"]
+            got = b["f0"][b["frame_offsets"][0]:b["frame_offsets"][1]]
+            v = want > 0
+            assert np.array_equal(got > 0, v) and np.max(np.abs(got[v] - want[v]) / want[v]) <= 1e-6
+    finally:
+        engine.pitch_set_refine("seeded")
+    with pytest.raises(Exception):
+        engine._check(engine._lib.pce_pitch_set_refine(engine._ctx, 7))

@@ -43,19 +43,24 @@ def test_mel_filterbank_known_values():
                                   dict(WW.DIMS["small"], n_layer=2), dict(WW.DIMS["medium"], n_layer=2),
                                   # 512 and 1280: the other widths the persistent 256 x 256 GEMM takes (2 / 5 column tiles per projection)
                                   dict(WW.DIMS["base"], n_layer=2), dict(n_mels=80, n_ctx=1500, n_state=1280, n_head=20, n_layer=1)])
-def test_encoder_matches_torch(engine, clips, dims):
+def test_encoder_matches_torch(engine, clips, dims, ops):
+    """Every width the GEMM / attention routing distinguishes, per operand type, against the fp32 restatement.  Bounds = what the
+    operand rounding allows after a stack of layers (measured, tools/operand_precision.py / DESIGN section 4: fp16 4.6e-4 rel-L2 at
+    Whisper-small depth, bf16 5.9e-3), with a margin of 3: fp16 1.5e-3 / 1.2e-2 sigma max, bf16 2e-2 / 6e-2 sigma max."""
     W = WW.synthetic_weights(dims)
     engine.upload(clips[:2], 16000)
     engine.logmel_run(dims["n_mels"])
     engine.whisper_load(dims, WW.pack(W, dims))
     engine.whisper_encode_run()
+    l2_bound, max_bound = ops["enc_l2"], ops["enc_max"]
     for i in range(2):
         got = engine.whisper_encode_fetch(i)
         want = WO.encoder_forward(WO.log_mel(clips[i], dims["n_mels"]), W, dims)
         assert got.shape == want.shape == (1500, dims["n_state"])
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
-        assert rel <= 2e-2, rel
-        assert np.max(np.abs(got - want)) <= 6e-2 * max(1.0, float(np.std(want)))
+        assert rel <= l2_bound, (ops["name"], rel)
+        worst = np.max(np.abs(got - want)) / max(1.0, float(np.std(want)))
+        assert worst <= max_bound, (ops["name"], worst)
 
 
 def test_dtw_indices_bit_exact(engine):
@@ -114,6 +119,47 @@ def test_forced_alignment_matches_torch(engine, clips, width, heads):
         jumps_g = got["time_indices"][np.r_[True, np.diff(got["text_indices"]) > 0]]
         jumps_w = tj[np.r_[True, np.diff(ti) > 0]]
         assert len(jumps_g) == len(jumps_w) and np.mean(np.abs(jumps_g - jumps_w) <= 1) >= 0.95          # observed: identical
+
+
+def test_forced_alignment_matches_transformers_token_timestamps(engine, ops):
+    """``pce_whisper_align_run`` against vectors computed by transformers' ``_extract_token_timestamps`` and its DTW port on the
+    transformers model's own cross-attentions (tests/golden/whisper_hf_align.npz, see its generating script): the cost matrix the DTW
+    runs on is the golden's normalised / median-filtered / head-averaged matrix (rows ``[sot_len:-1]``, negated) within the operand
+    type's rounding, and the alignment indices -- the DTW path and the token jump times -- are the golden's: identical with fp16
+    operands (the reference's arithmetic), at least 95 % within one frame (20 ms) with bf16.  Both head selections, both clips."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "whisper_hf_align.npz"))
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=77), WW.synthetic_decoder_weights(tdims, seed=78)
+    sot_len = int(g["sot_len"][0])
+    use = [synth.synth_clip(int(ci), seconds=float(sec)) for ci, sec in g["clips"]]
+    engine.upload(use, 16000)
+    engine.logmel_run(80)
+    engine.whisper_load(edims, WW.pack(We, edims))
+    engine.whisper_encode_run()
+    engine.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+    for name in ("upper_half", "picked"):
+        keys = [f"c{int(ci)}_{name}" for ci, _ in g["clips"]]
+        toks = [g[k + "_tokens"].tolist() for k in keys]
+        hm = np.zeros((2, 2), dtype=bool)
+        for l, h in g[keys[0] + "_heads"]:
+            hm[l, h] = True
+        res = engine.whisper_align(toks, [3000, 3000], sot_len, head_mask=hm, want_cost=True)
+        for k, got in zip(keys, res):
+            want_cost = -g[k + "_matrix"][sot_len:-1].astype(np.float64)
+            assert got["cost"].shape == want_cost.shape
+            rel = np.linalg.norm(got["cost"] - want_cost) / np.linalg.norm(want_cost)
+            assert rel <= (8e-3 if ops["name"] == "fp16" else 4e-2), (k, ops["name"], rel)
+            jumps = np.r_[True, np.diff(got["text_indices"]) > 0]
+            jt = got["time_indices"][jumps] * 0.02
+            wt = g[k + "_jump_times"]
+            assert len(jt) == len(wt) == len(toks[keys.index(k)]) - sot_len - 1
+            if ops["name"] == "fp16":
+                assert np.array_equal(got["text_indices"], g[k + "_text_idx"]) and np.array_equal(got["time_indices"], g[k + "_time_idx"]), k
+                assert np.array_equal(jt, wt), k
+            else:
+                assert np.mean(np.abs(jt - wt) <= 0.02 + 1e-9) >= 0.95, (k, float(np.mean(np.abs(jt - wt) <= 0.02 + 1e-9)))
 
 
 def test_median_filter_network_equals_generic_sort(engine, clips, monkeypatch):
@@ -527,11 +573,11 @@ def _attention_reference(q, k, v, causal, dtype="bfloat16"):
 
 
 @pytest.mark.parametrize("shape", [(2, 2, 1500, 1500, False), (3, 1, 77, 77, True), (2, 2, 40, 1500, False), (1, 1, 130, 65, False), (1, 1, 1, 1, True)])
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1])
 def test_attention_kernel_against_torch(engine, ops, shape, mode):
     """The attention kernel alone (self-test entry point): encoder shape, causal decoder prefix, decoder-over-audio cross attention,
     ragged lengths (a key tile with one key, a query block with two queries), a single token.  Modes: the kernel as the engine runs it
-    (softmax reference fixed after the first key tile), its exact running-maximum path, and the round-1 kernel.  Tolerance: P and the
+    (softmax reference fixed after the first key tile) and its exact running-maximum path.  Tolerance: P and the
     output are bf16 (2^-8 relative), the sums fp32: 1e-2 absolute on outputs that are convex combinations of unit-variance values."""
     clips, heads, q_len, k_len, causal = shape
     rng = np.random.default_rng(q_len * 7 + k_len)

@@ -97,3 +97,36 @@ def test_greedy_decoding_matches_transformers_model_and_logit_processors():
         assert got == want, (int(ci), got, want)
         new = want[len(g["initial"]):]
         assert new[0] >= rules["timestamp_begin"] and any(t < rules["eot"] for t in new)
+
+
+def test_find_alignment_chain_matches_transformers_token_timestamps():
+    """The middle of ``find_alignment`` -- alignment-head selection -> softmax -> std / mean normalisation over the token axis -> median
+    filter -> mean over heads -- and the DTW path / token jump times after it, against vectors computed by transformers'
+    ``_extract_token_timestamps`` and its DTW port on the transformers model's own cross-attentions (tests/golden/whisper_hf_align.npz;
+    the generating script explains the row-crop difference between the two recipes and how it is handled).  The restatement starts from
+    ITS OWN decoder (already cross-checked above), so this covers the whole alignment leg: same matrix (fp32 noise), same path, same
+    times, for the default upper-half heads and for a picked head list, on a 4 s and a 9 s clip."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "whisper_hf_align.npz"))
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=77), WW.synthetic_decoder_weights(tdims, seed=78)
+    sot_len = int(g["sot_len"][0])
+    for ci, seconds in g["clips"]:
+        enc = WO.encoder_forward(WO.log_mel(synth.synth_clip(int(ci), seconds=float(seconds)), 80), We, edims)
+        for name in ("upper_half", "picked"):
+            key = f"c{int(ci)}_{name}"
+            tokens = g[key + "_tokens"].tolist()
+            hm = np.zeros((2, 2), dtype=bool)
+            for l, h in g[key + "_heads"]:
+                hm[l, h] = True
+            cost, ti, tj, full = WO.find_alignment(tokens, enc, Wd, tdims, 3000, sot_len, head_mask=hm, want_matrix=True)
+            want = g[key + "_matrix"]
+            assert full.shape == want.shape == (len(tokens), 1500)
+            assert np.max(np.abs(full - want)) <= 2e-3, (key, float(np.max(np.abs(full - want))))
+            assert np.array_equal(ti, g[key + "_text_idx"]) and np.array_equal(tj, g[key + "_time_idx"]), key
+            jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+            assert np.array_equal(tj[jumps] * 0.02, g[key + "_jump_times"])
+            # the function's own return value (DTW over ALL rows: prompt rows and the last row included) from the same matrix
+            ai, aj = WO.dtw_path(-full.astype(np.float64))
+            aj_times = aj[np.pad(np.diff(ai), (1, 0), constant_values=1).astype(bool)] * 0.02
+            assert np.allclose(np.r_[aj_times, aj_times[-1]], g[key + "_all_rows_times"], atol=1e-6)
