@@ -58,6 +58,34 @@ class TranscribeOptions:
     sample_len: Optional[int] = None
     max_windows: int = 400
     seed: int = 0
+    min_word_duration: float = 0.02        # whisper_timestamped.transcribe's parameter of that name (0.02 s since its 1.11), see ensure_increasing_positions
+
+
+def ensure_increasing_positions(items: List[dict], min_duration: float = 0.0) -> None:
+    """Word (or segment) times in increasing order, every item at least ``min_duration`` long: whisper-timestamped's function of that
+    name, applied to the words with ``min_word_duration`` (third party, absent: restated from its published behaviour, parity
+    unpinned).  An item that starts before its predecessor ends is moved to the middle of the overlap (the predecessor is shortened) unless
+    that would leave the predecessor shorter than ``min_duration``, in which case it starts where the predecessor ends; an item not longer
+    than ``min_duration`` is stretched to it.  A DTW path that gives several tokens the same frame -- zero-length words the TextGrid writer
+    of the reference rejects (``textgrid.IntervalTier.add`` raises on overlap, use_whisper_timestamped.py:368-374) -- comes out as a run
+    of ``min_duration`` words."""
+    for _ in range(len(items) + 1):
+        modified_backward = False
+        previous_end = 0.0
+        for i, it in enumerate(items):
+            if it["start"] < previous_end and i > 0:
+                new_start = round((previous_end + it["start"]) / 2, 2)
+                if new_start < items[i - 1]["start"] + min_duration:
+                    new_start = previous_end
+                else:
+                    items[i - 1]["end"] = new_start
+                    modified_backward = True
+                it["start"] = new_start
+            if it["end"] <= it["start"] + min_duration:
+                it["end"] = it["start"] + min_duration
+            previous_end = it["end"]
+        if not modified_backward:
+            return
 
 
 def compression_ratio(text: str) -> float:
@@ -324,6 +352,20 @@ def transcribe_batch(engine, model, tokenizer, clips: Sequence[np.ndarray], opti
             log.warning("transcription stopped after %d windows with audio left (max_windows)", opt.max_windows)
     # ---- 4. finish: clamp, map back through the VAD cuts, round, texts
     for i in range(n):
+        for sg in results[i]["segments"]:
+            for w in sg["words"]:
+                if opt.trust_whisper_timestamps:
+                    w["start"] = min(max(w["start"], sg["start"]), sg["end"]); w["end"] = min(max(w["end"], w["start"]), sg["end"])
+        # back through the VAD cuts first (a cut maps everything behind the last speech region onto its end), THEN the minimum duration: the
+        # times the TextGrid writer sees are the ones that must not collide
+        k = cuts[i]
+        conv = (lambda t, e=False: k.to_original(t, e)) if k is not None else (lambda t, e=False: t)
+        for sg in results[i]["segments"]:
+            for w in sg["words"]:
+                w["start"], w["end"] = conv(w["start"]), conv(w["end"], True)
+        if opt.min_word_duration is not None:
+            ensure_increasing_positions([w for sg in results[i]["segments"] for w in sg["words"]],
+                                        opt.min_word_duration if opt.trust_whisper_timestamps else 0.0)
         out_segments = []
         for sid, sg in enumerate(results[i]["segments"]):
             sg.pop("_window", None)
@@ -332,20 +374,16 @@ def transcribe_batch(engine, model, tokenizer, clips: Sequence[np.ndarray], opti
             text = tokenizer.decode(toks)
             if not text.strip() and not sg["words"]:
                 continue
-            a, b = sg["start"], sg["end"]
-            for w in sg["words"]:
-                if opt.trust_whisper_timestamps:
-                    w["start"] = min(max(w["start"], a), b); w["end"] = min(max(w["end"], w["start"]), b)
+            a, b = conv(sg["start"]), conv(sg["end"], True)
             if sg["words"]:
                 if not opt.trust_whisper_timestamps:
                     a, b = sg["words"][0]["start"], sg["words"][-1]["end"]
-            k = cuts[i]
-            conv = (lambda t, e=False: k.to_original(t, e)) if k is not None else (lambda t, e=False: t)
-            seg = {"id": len(out_segments), "seek": sg["seek"], "start": round(conv(a), 2), "end": round(conv(b, True), 2), "text": text,
+                a, b = min(a, sg["words"][0]["start"]), max(b, sg["words"][-1]["end"])      # (words stretched to the minimum duration stay inside their segment)
+            seg = {"id": len(out_segments), "seek": sg["seek"], "start": round(a, 2), "end": round(b, 2), "text": text,
                    "tokens": list(toks), "temperature": sg["temperature"], "avg_logprob": sg["avg_logprob"],
                    "compression_ratio": sg["compression_ratio"], "no_speech_prob": sg["no_speech_prob"],
                    "confidence": _confidence([l for t, l in zip(toks, lps) if t < tokenizer.eot]) if opt.compute_word_confidence else 1.0,
-                   "words": [{"text": w["text"], "start": round(conv(w["start"]), 2), "end": round(conv(w["end"], True), 2), "confidence": w["confidence"]}
+                   "words": [{"text": w["text"], "start": round(w["start"], 2), "end": round(w["end"], 2), "confidence": w["confidence"]}
                              for w in sg["words"]]}
             out_segments.append(seg)
         results[i]["segments"] = out_segments

@@ -36,11 +36,18 @@ def write_wav(path, pcm, rate=16000):
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate); w.writeframes(np.asarray(pcm, dtype="<i2").tobytes())
 
 
-def write_model_dir(root: Path, name="medium", seed=79):
-    """A checkpoint directory as ``PCE_WHISPER_DIR`` expects it: <name>.npz + multilingual.tiktoken (toy sizes)."""
-    tk = toy_tokenizer()
+def write_model_dir(root: Path, name="medium", seed=79, merges=None, word_gain=1.0, eot_gain=1.0):
+    """A checkpoint directory as ``PCE_WHISPER_DIR`` expects it: <name>.npz + multilingual.tiktoken (toy sizes).
+    ``merges``: the multi-byte tokens of the vocabulary (default: MERGES); ``word_gain`` / ``eot_gain`` scale the embedding rows (= the
+    tied output projection) of the multi-byte tokens / of end-of-text: a random-init model that prefers whole words to single bytes and
+    does not stop at once produces TextGrids with many words and pauses, which the end-to-end tests need (tests/test_gpu_c5.py)."""
+    tk = toy_tokenizer() if merges is None else WhisperTokenizer.toy(merges, language="fr")
     tdims = dict(n_vocab=tk.n_vocab, n_text_ctx=128, n_state=128, n_head=2, n_layer=2)
     enc, dec = WW.synthetic_weights(EDIMS, seed=77), WW.greedy_test_decoder_weights(tdims, seed=seed)
+    if word_gain != 1.0 or eot_gain != 1.0:
+        emb = dec["token_embedding.weight"].copy()
+        emb[256:tk.eot] *= word_gain; emb[tk.eot] *= eot_gain
+        dec["token_embedding.weight"] = emb
     root.mkdir(parents=True, exist_ok=True)
     np.savez(root / f"{name}.npz", **{"encoder." + k: v for k, v in enc.items()}, **{"decoder." + k: v for k, v in dec.items()})
     with open(root / "multilingual.tiktoken", "wb") as f:
