@@ -317,13 +317,18 @@ int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_
                                int32_t *next_tokens /* [clips] */, float *next_logprobs /* [clips] or NULL */,
                                float *probe_prob /* [clips] or NULL */);
 
-/* Operand type of every Whisper / BERT matrix product (round 3).  PCE_OPERANDS_FP16 (default): fp16 operands, the reference's own
+/* Operand type of every Whisper / BERT matrix product (round 3).  Default since round 4: PCE_OPERANDS_F16_RESID16 (below; PCE_WHISPER_OPERANDS=fp16
+ * or bf16 in the environment at pce_create selects another default).  PCE_OPERANDS_FP16: fp16 operands, the reference's own
  * arithmetic (openai-whisper runs in half precision: transcribe's fp16=True default behind
  * Code/Aligners/use_whisper_timestamped.py:163).  PCE_OPERANDS_BF16 (PCE_WHISPER_OPERANDS=bf16 in the environment at pce_create, or
  * this call): bf16 operands, 8 instead of 11 significand bits, about 3 % faster end to end (the MFMA rate is the same; the clock is not).
  * fp32 accumulation, fp32 LayerNorm / softmax statistics and an fp32 residual stream in both.  The two builds keep separate state:
- * call this BEFORE pce_whisper_load / pce_whisper_decoder_load / pce_bert_load / pce_logmel_run, and load again after switching. */
-enum { PCE_OPERANDS_BF16 = 0, PCE_OPERANDS_FP16 = 1 };
+ * call this BEFORE pce_whisper_load / pce_whisper_decoder_load / pce_bert_load / pce_logmel_run, and load again after switching.
+ * PCE_OPERANDS_F16_RESID16 (round 4): the fp16 build with the encoder's residual stream kept in fp16 as well -- openai-whisper's own
+ * `x = x + attn(...)`, `x = x + mlp(...)` are fp16 + fp16 -> fp16, only LayerNorm computes in fp32 (model.py) -- which cuts the bytes of the
+ * residual / LayerNorm passes from 22 to 16 per element and layer on the batched encoder path; same state slot as PCE_OPERANDS_FP16 (no
+ * reload needed between the two), pce_whisper_get_operands returns the value that was set. */
+enum { PCE_OPERANDS_BF16 = 0, PCE_OPERANDS_FP16 = 1, PCE_OPERANDS_F16_RESID16 = 2 };
 int pce_whisper_set_operands(pce_ctx *ctx, int32_t operand_type);
 int pce_whisper_get_operands(pce_ctx *ctx);
 

@@ -121,7 +121,14 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->en_cpb = getenv("PCE_EN_CPB") ? atoi(getenv("PCE_EN_CPB")) : 0;
     c->gemm_skinny = !(getenv("PCE_GEMM_SKINNY") && atoi(getenv("PCE_GEMM_SKINNY")) == 0);
     // default: fp16 operands, the reference's own arithmetic (and the closer of the two to the fp32 restatement: DESIGN.md section 4)
-    c->whisper_ops = (getenv("PCE_WHISPER_OPERANDS") && !strcmp(getenv("PCE_WHISPER_OPERANDS"), "bf16")) ? 0 : 1;
+    {
+        const char *ops = getenv("PCE_WHISPER_OPERANDS");
+        // default (round 4): fp16 operands AND the fp16 residual stream, the reference's own arithmetic end to end (openai-whisper fp16=True);
+        // measured against the fp32 restatement at Whisper-small depth (tools/operand_precision.py, profiles/r04): encoder rel-L2 1.0e-3,
+        // every word boundary identical, no greedy flip in 2 112 steps; "fp16" keeps the fp32 stream (4.6e-4), "bf16" the round-1 / 2 arithmetic
+        c->whisper_ops = (ops && !strcmp(ops, "bf16")) ? 0 : (ops && !strcmp(ops, "fp16")) ? 1 : 2;
+        c->resid16 = c->whisper_ops == 2;
+    }
     c->pitch_refine_praat = getenv("PCE_PITCH_REFINE") && !strcmp(getenv("PCE_PITCH_REFINE"), "praat");
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);

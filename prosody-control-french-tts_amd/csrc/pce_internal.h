@@ -123,7 +123,8 @@ struct pce_ctx {
     // whisper / BERT state, opaque (pce_whisper_impl.inc): one slot per operand-type build (0: bf16, 1: fp16); whisper_ops selects the build the
     // entry points of include/pce.h forward to (pce_whisper_set_operands, or PCE_WHISPER_OPERANDS=fp16 at pce_create)
     void *whisper_slot[2] = {nullptr, nullptr};
-    int whisper_ops = 1;                 // (pce_create: fp16 unless PCE_WHISPER_OPERANDS=bf16)
+    int whisper_ops = 2;                 // (pce_create: 2 = the fp16 build + resid16 unless PCE_WHISPER_OPERANDS=bf16 / fp16)
+    bool resid16 = true;                 // the batched encoder path keeps its residual stream in 16 bits (fp16 build only)
 
     // asynchronous statistics fetch (pce_stats_enqueue / pce_stats_wait)
     struct StatSlot {

@@ -4,7 +4,7 @@
 #include "pce_internal.h"
 
 #define PCE_BOTH(ret, name, params)  extern "C" { ret name##_bf16 params; ret name##_f16 params; }
-#define PCE_FWD(name, ...) ((c && c->whisper_ops == 1) ? name##_f16(__VA_ARGS__) : name##_bf16(__VA_ARGS__))
+#define PCE_FWD(name, ...) ((c && c->whisper_ops >= 1) ? name##_f16(__VA_ARGS__) : name##_bf16(__VA_ARGS__))
 
 PCE_BOTH(int, pce_logmel_run, (pce_ctx *, int32_t))
 PCE_BOTH(int, pce_logmel_run_at, (pce_ctx *, int32_t, const int64_t *))
@@ -34,8 +34,10 @@ extern "C" {
 int pce_whisper_set_operands(pce_ctx *c, int32_t operand_type)
 {
     if (!c) return PCE_E_INVALID;
-    if (operand_type != PCE_OPERANDS_BF16 && operand_type != PCE_OPERANDS_FP16) return pce_fail(c, PCE_E_INVALID, "operand type %d (0 = bf16, 1 = fp16)", operand_type);
+    if (operand_type != PCE_OPERANDS_BF16 && operand_type != PCE_OPERANDS_FP16 && operand_type != PCE_OPERANDS_F16_RESID16)
+        return pce_fail(c, PCE_E_INVALID, "operand type %d (0 = bf16, 1 = fp16, 2 = fp16 with the fp16 residual stream)", operand_type);
     c->whisper_ops = operand_type;
+    c->resid16 = operand_type == PCE_OPERANDS_F16_RESID16;
     return PCE_OK;
 }
 int pce_whisper_get_operands(pce_ctx *c) { return c ? c->whisper_ops : PCE_E_INVALID; }

@@ -412,16 +412,16 @@ class ProsodyEngine:
     def whisper_set_operands(self, kind: str):
         """``"fp16"`` (default: the reference's own arithmetic, openai-whisper's fp16=True) or ``"bf16"``.  The two builds keep
         separate state: select BEFORE loading weights / running the log-mel, and load again after switching."""
-        code = {"bf16": 0, "fp16": 1}[str(kind).lower()]
+        code = {"bf16": 0, "fp16": 1, "fp16-resid16": 2}[str(kind).lower()]       # fp16-resid16: fp16 operands AND an fp16 residual stream in the batched encoder
         self._check(self._lib.pce_whisper_set_operands(self._ctx, code))
 
     @property
     def whisper_operands(self) -> str:
-        return "fp16" if self._lib.pce_whisper_get_operands(self._ctx) == 1 else "bf16"
+        return {0: "bf16", 1: "fp16", 2: "fp16-resid16"}[self._lib.pce_whisper_get_operands(self._ctx)]
 
     def _op_dtype(self):
         import torch
-        return torch.float16 if self.whisper_operands == "fp16" else torch.bfloat16
+        return torch.bfloat16 if self.whisper_operands == "bf16" else torch.float16
 
     def whisper_load(self, dims: dict, weights: np.ndarray):
         """``dims``: n_mels, n_ctx, n_state, n_head, n_layer; ``weights``: float32 blob in the order of include/pce.h."""

@@ -21,11 +21,14 @@ def engine():
     eng.close()
 
 
+DEFAULT_OPERANDS = "fp16-resid16"
+
+
 @pytest.fixture(autouse=True)
 def _default_operands(request):
-    """GPU tests start on the default operand type (fp16) whatever the previous test selected."""
+    """GPU tests start on the product's default operand mode (fp16 operands + fp16 residual stream) whatever the previous test selected."""
     if "engine" in request.fixturenames:
-        request.getfixturevalue("engine").whisper_set_operands(os.environ.get("PCE_TEST_OPERANDS", "fp16"))
+        request.getfixturevalue("engine").whisper_set_operands(os.environ.get("PCE_TEST_OPERANDS", DEFAULT_OPERANDS))
     yield
 
 
@@ -33,14 +36,16 @@ def _default_operands(request):
 # enc_l2 / enc_max: a whole encoder stack against the fp32 restatement (relative L2; worst element in units of the output's sigma)
 OPERANDS = {"bf16": dict(torch="bfloat16", l2=4e-3, rel=2.0 ** -7, abs=1e-2, attn_abs=1e-2, attn_l2=6e-3, enc_l2=2e-2, enc_max=6e-2),
             "fp16": dict(torch="float16", l2=6e-4, rel=2.0 ** -10, abs=2e-3, attn_abs=2e-3, attn_l2=1e-3, enc_l2=1.5e-3, enc_max=1.2e-2)}
+# the product default: fp16 operands + the encoder's residual stream in fp16 (24 more roundings at Whisper-small depth: measured 1.04e-3 / 0.009 sigma)
+OPERANDS["fp16-resid16"] = dict(OPERANDS["fp16"], enc_l2=2.5e-3, enc_max=2.5e-2)
 
 
-@pytest.fixture(params=["fp16", "bf16"])
+@pytest.fixture(params=["fp16-resid16", "fp16", "bf16"])
 def ops(request, engine):
     """Runs a test once per operand type of the Whisper / BERT kernels; yields that type's name, torch dtype name and bounds."""
     engine.whisper_set_operands(request.param)
     yield dict(OPERANDS[request.param], name=request.param)
-    engine.whisper_set_operands("fp16")
+    engine.whisper_set_operands(DEFAULT_OPERANDS)
 
 
 @pytest.fixture(scope="session")

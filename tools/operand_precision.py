@@ -1,4 +1,4 @@
-"""bf16 vs fp16 operands at full depth (Whisper-small, 12 + 12 layers, fixed-seed random-init weights: no trained checkpoint exists
+"""bf16 vs fp16 operands vs fp16 operands + fp16 residual stream at full depth (Whisper-small, 12 + 12 layers, fixed-seed random-init weights: no trained checkpoint exists
 offline) against the float32 restatement (oracle/whisper_oracle.py):
   * encoder output: relative L2 and maximum error, 4 ten-second clips
   * alignment cost matrix: relative L2; word-boundary frames identical / within one 20 ms step of the fp32 path
@@ -36,7 +36,7 @@ print(f"fp32 restatement: {time.time() - t0:.0f} s", file=sys.stderr)
 mask = DEC.vocab_mask(tdims["n_vocab"], rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
 out = {"model": "whisper-small dims, random-init weights (seeded), n_vocab 2048", "clips_encoder": 4, "clips_decisions": n_dec}
 eng = pkg.ProsodyEngine(0)
-for kind in ("bf16", "fp16"):
+for kind in ("bf16", "fp16", "fp16-resid16"):
     eng.whisper_set_operands(kind)
     eng.upload(clips4, 16000); eng.logmel_run(80)
     eng.whisper_load(dims, WW.pack(W, dims)); eng.whisper_encode_run()
