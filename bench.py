@@ -34,14 +34,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (never the 2:1-sparsity figure)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s fp32 vector rate (AMD's MI355X fp64 vector figure; the guide has no fp64 row)
 VALU_F64_PEAK_TFLOPS = 78.6     # fp64 vector peak (79 TF/s)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 COMPOSITE = ("whisper_encoder", "whisper_align", "bert_forward", "whisper_decode_step", "whisper_decode_loop")   # brackets around several launches
 
 
 def load_pmc_traffic(workload):
     """HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 for the gfx950 wide-read
     under-count + WRITE_SIZE, KB -> B; tools/pmc_traffic.py), committed under profiles/."""
-    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r02")):        # (the previous round's passes until this round's are committed)
+    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r03")):        # (the previous round's passes until this round's are committed)
         try:
             with open(os.path.join(d, f"pmc_traffic_{workload}.json")) as f:
                 out = json.load(f)["bytes_per_launch"]
@@ -203,6 +203,8 @@ def main():
                     "(double buffered) for `streamed_value`; 0 = skip")
     ap.add_argument("--transcribe-steps", type=int, default=32, help="c3: free-running decoding steps per window of the extra `transcribe` "
                     "measurement (log-mel + encoder + device-resident decoding loop + forced alignment; never `value`); 0 = skip")
+    ap.add_argument("--medium-steps", type=int, default=2, help="c3 with --whisper-model small on one GPU: extra steps with Whisper-medium dims (the "
+                    "reference's default model) for the `medium` object; 0 = skip")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the rank launcher and the exchange (gloo, no engine, no throughput)")
     args = ap.parse_args()
@@ -315,6 +317,8 @@ def run_rank(args, world, rank, local_rank):
                         1.0 - en["n_loud"] / np.maximum(en["n"], 1), en["n"] / float(rate), pi["n_voiced"].astype(np.float64)], axis=1)
         return shard.allgather_records(rec, counts)
 
+    done_at = []                                                   # host clock when a step's statistics had arrived (step_ms_spread)
+
     def run_steps(k, before_launch=None):
         rec = None
         for i in range(k):
@@ -322,9 +326,9 @@ def run_rank(args, world, rank, local_rank):
                 before_launch(i)
             launch(i & 1)
             if i > 0:
-                rec = finish((i - 1) & 1)
+                rec = finish((i - 1) & 1); done_at.append(time.perf_counter())
         if k > 0:
-            rec = finish((k - 1) & 1)
+            rec = finish((k - 1) & 1); done_at.append(time.perf_counter())
         return rec
 
     def fence():
@@ -338,10 +342,17 @@ def run_rank(args, world, rank, local_rank):
         eng.profile_enable(True)
         eng.profile_reset()
     fence()
+    done_at.clear()
     t0 = time.perf_counter()
     rec = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    # spread of the K timed steps: intervals between the arrivals of consecutive steps' statistics on the host (the steps are software
+    # pipelined, so an interval is one step of device time; the first one also holds the pipeline fill).  No extra synchronisation, no extra events.
+    iv = np.diff(np.array([t0] + done_at[:args.steps])) * 1e3
+    spread = ({"min": float(iv[1:].min()), "median": float(np.median(iv[1:])), "max": float(iv[1:].max()), "first": float(iv[0]), "n": int(len(iv) - 1),
+               "what": "ms between the arrivals of consecutive steps' statistics on the host inside the timed region (first = pipeline fill + step 1)"}
+              if len(iv) > 1 else None)
     prof = eng.profile() if not args.no_profile else {}
     eng.profile_enable(False)
 
@@ -441,6 +452,51 @@ def run_rank(args, world, rank, local_rank):
                                                                      "whisper_encoder", "whisper_align", "k_gemm_flat:xkv")}}
         except Exception as e:                                      # never lose the main line over the extra measurement
             transcribe = {"error": repr(e)}
+
+    # The reference's default model (config.yaml:15 `whisper_model: medium`; BASELINE.json's C3 names small): the same step with Whisper-medium
+    # dims (24 + 24 layers, d = 1024, 16 heads).  Extra measurement, never `value`.  One layer's random tensors are shared by all layers (timing
+    # does not depend on the values; 769 M fresh random numbers would cost more host time than the measurement).
+    medium = None
+    if wdims and args.whisper_model == "small" and args.medium_steps > 0 and world == 1:
+        try:
+            md, mt = WW.DIMS["medium"], WW.TEXT_DIMS["medium"]
+            def shared(make, dims):
+                one = make(dict(dims, n_layer=1))
+                full = dict(one)
+                for l in range(1, dims["n_layer"]):
+                    for k, v in one.items():
+                        if k.startswith("blocks.0."):
+                            full[f"blocks.{l}." + k[len("blocks.0."):]] = v
+                return full
+            eng.whisper_load(md, WW.pack(shared(WW.synthetic_weights, md), md))
+            eng.whisper_decoder_load(mt, WW.pack_decoder(shared(WW.synthetic_decoder_weights, mt), mt))
+            m_tokens = [[int(t) % mt["n_vocab"] for t in toks] for toks in align_tokens]
+
+            def m_step():
+                eng.logmel_run(md["n_mels"]); eng.whisper_encode_run(); eng.whisper_align_run(m_tokens, align_frames, sot_len)
+                eng.energy_run(sl, 500); eng.lufs_run(sl); eng.pitch_run(sl, params); eng.stft_db_run(1024, 256)
+            m_step(); fence()
+            eng.profile_enable(True); eng.profile_reset()
+            tm0 = time.perf_counter()
+            for _ in range(args.medium_steps):
+                m_step()
+            fence()
+            tm = (time.perf_counter() - tm0) / args.medium_steps
+            pr = eng.profile(); eng.profile_enable(False)
+            m_flop = args.clips * (2.0 * 3000 * md["n_state"] * 240 + 2.0 * 1500 * md["n_state"] * 3 * md["n_state"]
+                                   + md["n_layer"] * (2.0 * 1500 * md["n_state"] * 3 * md["n_state"] + 4.0 * 1500 * 1500 * md["n_state"]
+                                                      + 2.0 * 1500 * md["n_state"] ** 2 + 16.0 * 1500 * md["n_state"] ** 2))
+            enc_ms = pr.get("whisper_encoder", {}).get("total_ms", 0.0) / args.medium_steps
+            gf = [(k, v) for k, v in pr.items() if k.startswith("k_gemm_flat")]
+            g_ms, g_fl = sum(v["total_ms"] for _, v in gf), sum(v.get("flops", 0.0) for _, v in gf)
+            medium = {"what": f"the C3 step with Whisper-medium dims (the reference's default, config.yaml:15): {args.clips} clips, {args.medium_steps} steps, "
+                              "random-init weights (one layer's tensors shared by all layers)", "ms_per_step": tm * 1e3,
+                      "x_real_time": args.clips * args.seconds / tm, "encoder_ms": enc_ms, "encoder_flops": m_flop,
+                      "encoder_tflops": m_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else None,
+                      "k_gemm_flat_tflops": g_fl / (g_ms * 1e-3) / 1e12 if g_ms else None,
+                      "k_gemm_flat_frac": g_fl / (g_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if g_ms else None}
+        except Exception as e:                                      # never lose the main line over the extra measurement
+            medium = {"error": repr(e)}
 
     if rank == 0:
         # per-kernel figures (HIP events on the engine's stream around every launch)
@@ -561,14 +617,16 @@ def run_rank(args, world, rank, local_rank):
             "metric": ("audio-seconds/sec prosody+align throughput, 16 kHz French" if wdims
                        else "audio-seconds/sec prosody throughput (no alignment leg), 16 kHz French"),
             "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_spread": spread,
+            "timing_note": ("the timed region carries the per-kernel HIP event pairs of the profile (about 0.5 % of a step: --no-profile runs without them)"
+                            if not args.no_profile else "no per-kernel events in the timed region"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": f"{eng.whisper_operands} (MFMA legs) + f64 (F0 / LUFS)" if wdims else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, " + what,
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)"},
             "roofline": roofline, "mfma_floor": floor, "gemm_shapes": gemm_shapes, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
-            "streamed_value": streamed, "transcribe": transcribe, "device": info["name"], "host_cores": os.cpu_count(),
+            "streamed_value": streamed, "transcribe": transcribe, "medium": medium, "device": info["name"], "host_cores": os.cpu_count(),
         }))
     eng.close()
     if world > 1:
