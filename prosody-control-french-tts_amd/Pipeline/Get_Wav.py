@@ -1,7 +1,7 @@
 """SSML fragment formatting of the legacy pipeline (``Code/Pipeline/Get_Wav.py:8-66``).
 
 Only the string-building half is mirrored: ``get_wav`` itself calls the Azure synthesiser, which
-is out of scope (DESIGN.md section 7).  ``create_ssml_fragment`` turns one syntagme's adjustment
+is out of scope (DESIGN.md section 8).  ``create_ssml_fragment`` turns one syntagme's adjustment
 percentages and its natural pause into either ``<break time='Nms'/>`` (empty text) or a
 ``<prosody ...>`` element, with the reference's compressions (|rate|^0.8 capped at +2, sqrt of
 |pitch|), its pause rule (ms / 3, scaled by ``pause_coef``, clamped to [min_pause, max_pause],

@@ -120,7 +120,6 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->gemm_flat = !(getenv("PCE_GEMM_FLAT") && atoi(getenv("PCE_GEMM_FLAT")) == 0);
     c->en_cpb = getenv("PCE_EN_CPB") ? atoi(getenv("PCE_EN_CPB")) : 0;
     c->gemm_skinny = !(getenv("PCE_GEMM_SKINNY") && atoi(getenv("PCE_GEMM_SKINNY")) == 0);
-    // default: fp16 operands, the reference's own arithmetic (and the closer of the two to the fp32 restatement: DESIGN.md section 4)
     {
         const char *ops = getenv("PCE_WHISPER_OPERANDS");
         // default (round 4): fp16 operands AND the fp16 residual stream, the reference's own arithmetic end to end (openai-whisper fp16=True);
