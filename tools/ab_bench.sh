@@ -9,7 +9,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-ARGS=${AB_BENCH_ARGS:---cpu-clips 0 --streamed-steps 0 --transcribe-steps 0 --steps 5}
+ARGS=${AB_BENCH_ARGS:---cpu-clips 0 --streamed-steps 0 --transcribe-steps 0 --medium-steps 0 --steps 5}
 mkdir -p gpurun_out/ab
 for round in 1 2; do
   for tag in "$@"; do
