@@ -126,6 +126,11 @@ def test_c5_full_voice_end_to_end_and_ssml_diff_against_the_cpu_path(engine, tmp
         p = tmp_path / ("want_" + name)
         df.to_csv(p, index=False)
         assert (res_dir / name).read_text(encoding="utf-8") == p.read_text(encoding="utf-8"), name
+    # ---- the path the ranks of a multi-GPU run take (local block, run_sharded, the records through allgather_records) at world size 1: same three files
+    sharded = AP.AudioPipeline(VOICE, dict(cfg, out_dir="Out_sharded", force_sharded_path=True), base=tmp_path, engine=engine)
+    sharded.measure_prosody_and_build_ssml()
+    for name in ("BDD_ssml.csv", "BDD_syntagme_ssml.csv", "BDD_syntagme_for_synth.csv"):
+        assert (sharded.results_dir / name).read_text(encoding="utf-8") == (res_dir / name).read_text(encoding="utf-8"), name
     # ---- the last step: OUT.wav transcribed, results moved beside it; the run's configuration recorded
     assert (res_dir / "OUT.TextGrid").exists() and (res_dir / "OUT.txt").exists() and (res_dir / "used_config.yaml").exists()
     # ---- break prediction over the voice's cleaned transcriptions
