@@ -319,3 +319,31 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-launcher"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert bad.returncode != 0 and b"WORLD_SIZE" in bad.stderr
+
+
+def test_failure_flags_without_a_process_group():
+    """The single-process forms of the rank-failure plumbing: a flagged block raises PeerFailure, ``agreed`` lets a local exception through (and a
+    clean ``sys.exit(0)``), ``barrier(ok)`` returns its argument, and ``run_sharded`` re-raises the measurement error itself."""
+    from prosody_control_french_tts_amd import shard, tagger as T
+    assert shard.barrier(True) is True and shard.barrier(False) is False
+    with pytest.raises(shard.PeerFailure):
+        shard.allgather_records(np.zeros((0, 3)), [0], failed=True)
+    with pytest.raises(KeyError):
+        with shard.agreed():
+            raise KeyError("local")
+    with pytest.raises(SystemExit) as e:
+        with shard.agreed(only_rank=0) as sec:
+            assert sec.mine
+            sys.exit(0)
+    assert e.value.code == 0
+
+    class Broken(T.MeasurementSource):
+        def median_pitch(self, segment, t0=0.0, t1=None): raise OSError("device lost")
+        def lufs(self, kind, segment, t0=0.0, t1=None): raise OSError("device lost")
+        def duration(self, kind, segment): raise OSError("device lost")
+        def part_duration(self, kind, segment, t0=0.0, t1=None): raise OSError("device lost")
+
+    tg = T.SsmlTagger(T.ProsodySettings.from_config({}), "fr-FR-HenriNeural")
+    segs = [T.SegmentInput("segment_ph1", [(0.0, 0.4, "bonjour"), (0.4, 0.6, " "), (0.6, 1.0, "monde.")])]
+    with pytest.raises(OSError, match="device lost"):
+        tg.run_sharded(segs, Broken(), 0, 1, shard.allgather_records)
