@@ -592,7 +592,9 @@ def run_rank(args, world, rank, local_rank):
                             "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": tr, "avg_launch_ms": k0["avg_ms"],
                             "launches_per_step": k0["launches_per_step"], "algorithmic_flops_per_launch": k0["flops_per_launch"],
                             "note": "dominant kernel by device time per step; achieved = 2MNK (mean over this kernel's launches in a step: "
-                                    "conv, QKV / out-proj / fc1 / fc2 shapes) / its mean launch duration; dense bf16 peak 2.5 PFLOP/s at 2.4 GHz"}
+                                    "conv, QKV / out-proj / fc1 / fc2 shapes) / its mean launch duration; dense bf16 peak 2.5 PFLOP/s at 2.4 GHz.  "
+                                    "The MFMA kernels run against the power limit: the same instruction streams on all-zero operands are 14-20 % faster and the "
+                                    "in-kernel clock under this load is 2.15 GHz (profiles/r04/power_probe.txt, gemm_flat_lab.txt)"}
             elif k0["kernel"] in kernel_stage_bytes:
                 sname, nbytes = kernel_stage_bytes[k0["kernel"]]
                 ach = nbytes / (k0["avg_ms"] * 1e-3) / 1e9
