@@ -205,6 +205,10 @@ def main():
                     "measurement (log-mel + encoder + device-resident decoding loop + forced alignment; never `value`); 0 = skip")
     ap.add_argument("--medium-steps", type=int, default=2, help="c3 with --whisper-model small on one GPU: extra steps with Whisper-medium dims (the "
                     "reference's default model) for the `medium` object; 0 = skip")
+    ap.add_argument("--framing-clips", type=int, default=1250, help="clips of the extra `framing_hbm` measurement (k_energy / k_frame_energy beyond the Infinity "
+                    "Cache: the per-GPU shard of BASELINE config 4); 0 = skip")
+    ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered per-utterance records of the last timed step to this .npy file")
+    ap.add_argument("--first-clip", type=int, default=0, help="seed offset of the first synthetic clip (rank r owns first + [r*clips, (r+1)*clips))")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the rank launcher and the exchange (gloo, no engine, no throughput)")
     args = ap.parse_args()
@@ -252,7 +256,7 @@ def run_rank(args, world, rank, local_rank):
 
     import prosody_control_french_tts_amd as pkg
     # synthetic data of the workload's shape; rank r owns clips [r*clips, (r+1)*clips) (weak scaling)
-    clips = synth.synth_batch(args.clips, args.seconds, rate, first=rank * args.clips)
+    clips = synth.synth_batch(args.clips, args.seconds, rate, first=args.first_clip + rank * args.clips)
     wdims = tdims = None
     if args.workload == "c3":
         from prosody_control_french_tts_amd import whisper_weights as WW
@@ -269,20 +273,23 @@ def run_rank(args, world, rank, local_rank):
         cpu = cpu_prosody_baseline(clips, rate, args.cpu_clips)
         if wdims:
             wh = cpu_whisper_baseline(clips, rate, args.whisper_model, W_enc, W_dec, wdims, tdims, align_tokens, sot_len)
-            per_clip = cpu["seconds"] / cpu["clips"] + wh["seconds_per_clip"]
-            cpu["prosody_leg"] = {"value": cpu["value"], "cores": 1, "sample": cpu["sample"]}
-            cpu["whisper_leg"] = wh
+            # both legs on ALL host cores, side by side (never one leg on one thread added to the other on 128): the prosody leg as
+            # utterance-parallel worker processes, the Whisper leg on torch's intra-op threads; the one-thread prosody rate stays beside them
+            ac = cpu.get("all_cores", {})
+            pros_rate = ac.get("value") or cpu["value"]
+            pros_cores = ac.get("processes") or 1
+            per_clip = args.seconds / pros_rate + wh["seconds_per_clip"]
+            cpu["legs"] = {"prosody": {"value": pros_rate, "unit": "audio-seconds/sec", "cores": pros_cores, "what": "oracle/pce_oracle.c + numpy, one worker process per core"},
+                           "prosody_one_thread": {"value": cpu["value"], "unit": "audio-seconds/sec", "cores": 1},
+                           "whisper": dict(wh, value=args.seconds / wh["seconds_per_clip"], unit="audio-seconds/sec", cores=wh["threads"])}
             cpu["value"] = args.seconds / per_clip
-            cpu["cores"] = wh["threads"]
-            cpu["sample"] = (f"C3 per-clip time = prosody leg ({cpu['clips']} clips, C oracle, one thread) + Whisper leg ({wh['clips']} clips, "
-                             f"{wh['seconds']:.1f} s, torch CPU float32 on {wh['threads']} threads); {cpu['seconds'] + wh['seconds']:.1f} s of CPU work")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+            cpu["cores"] = max(pros_cores, wh["threads"])
+            cpu["sample"] = (f"C3 per-clip time = prosody leg ({cpu['clips']} clips, C oracle, {pros_cores} worker processes: {pros_rate:.0f} x real time) + Whisper leg "
+                             f"({wh['clips']} clips, {wh['seconds']:.1f} s, torch CPU float32 on {wh['threads']} threads: {args.seconds / wh['seconds_per_clip']:.2f} x real time); "
+                             f"each leg uses the host's cores its own way, `legs` has them side by side; {cpu['seconds'] + wh['seconds']:.1f} s of CPU work")
+    # one process per GPU over RCCL ("nccl"); PCE_DIST_BACKEND=gloo + PCE_RANK_DEVICE=0 run the same ranks on ONE device (shard.init_from_env)
+    _, _, local_rank = shard.init_from_env()
+    torch.cuda.set_device(local_rank)
     eng = pkg.ProsodyEngine(local_rank)
     eng.upload(clips, rate)                      # inputs resident in HBM before the timed region
     sl = eng.whole_clip_slices()
@@ -303,13 +310,19 @@ def run_rank(args, world, rank, local_rank):
             eng.logmel_run(wdims["n_mels"])
             eng.whisper_encode_run()
             eng.whisper_align_run(align_tokens, align_frames, sot_len)   # teacher-forced decoder + cross-attention weights + DTW
+            eng.whisper_align_paths_enqueue(slot)                        # every clip's (token, frame) path -> pinned host memory, asynchronously
         eng.energy_run(sl, 500)
         eng.lufs_run(sl)
         eng.pitch_run(sl, params)
         eng.stft_db_run(1024, 256)
         eng.stats_enqueue(slot)
 
+    path_steps = []                                                # DTW path steps that reached the host per step (c3)
+
     def finish(slot):
+        if wdims:
+            pl, _, _ = eng.whisper_align_paths_wait(slot)           # what a pipeline writes TextGrids from: the alignment leaves the device inside the step
+            path_steps.append(int(pl.sum()))
         r = eng.stats_wait(slot)
         en, lu, pi = r["energy"], r["lufs"][0], r["pitch"]
         # per-utterance record: [median F0, LUFS, rms, peak, silence ratio, duration, n_voiced]
@@ -356,12 +369,14 @@ def run_rank(args, world, rank, local_rank):
     prof = eng.profile() if not args.no_profile else {}
     eng.profile_enable(False)
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda" if world == 1 or dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
     audio_seconds = args.clips * args.seconds * world * args.steps
     assert rec.shape == (args.clips * world, 7)
+    if args.dump_records and rank == 0:
+        np.save(args.dump_records, rec)                              # the gathered per-utterance records of the last timed step (tests compare world 2 with world 1)
 
     # H2D-inclusive rate: the batch arrives from pinned host memory every step, double buffered (the copy of batch i+1
     # runs on a copy stream beside the kernels of batch i; the engine adopts the device buffer without a copy).
@@ -498,6 +513,37 @@ def run_rank(args, world, rank, local_rank):
         except Exception as e:                                      # never lose the main line over the extra measurement
             medium = {"error": repr(e)}
 
+    # north_star's ">= 70 % of the HBM roofline on the framing kernels", measured where it means HBM: the C2 / C3 batch (82 MB) sits inside the
+    # 256 MB Infinity Cache, so a repeated launch on it is served on-die and launch-shaped; the rank-local shard of BASELINE config 4
+    # (10 000 clips over 8 GPUs = 1 250 x 10 s = 400 MB) is beyond it.  k_energy (R3 / R7: seven exact integer reductions per sample) and
+    # k_frame_energy (the VAD's 50 ms windows) over that shard, HIP events on the engine's stream.  Last measurement: it replaces the resident batch.
+    framing = None
+    if args.framing_clips > 0 and rank == 0:
+        try:
+            fclips = [clips[i % len(clips)] for i in range(args.framing_clips)]
+            eng.upload(fclips, rate)
+            fsl = eng.whole_clip_slices()
+            fbytes = 2.0 * sum(len(c) for c in fclips)
+            framing = {"what": f"{args.framing_clips} x {args.seconds:g} s clips ({fbytes / 1e6:.0f} MB of int16 PCM, the per-GPU shard of BASELINE config 4: beyond the 256 MB "
+                               "Infinity Cache); algorithmic bytes = PCM in + results out; 30 launches each after 5 untimed, HIP events",
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": {}}
+            for name, run, extra in (("k_energy", lambda: eng.energy_run(fsl, 500), 0.0),
+                                     ("k_frame_energy", lambda: eng.frame_energy_run(800, 800, requantize=False), args.framing_clips * (n_samples // 800) * 12.0)):
+                for _ in range(5):
+                    run()
+                eng.sync(); eng.profile_enable(True); eng.profile_reset()
+                for _ in range(30):
+                    run()
+                eng.sync()
+                pk = eng.profile()[name]; eng.profile_enable(False)
+                ms = pk["total_ms"] / pk["launches"]
+                ach = (fbytes + extra) / (ms * 1e-3) / 1e9
+                framing["kernels"][name] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes": fbytes + extra, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+            framing["achieved"] = min(k["achieved"] for k in framing["kernels"].values())
+            framing["frac"] = framing["achieved"] / HBM_PEAK_GBS       # the slower of the two
+        except Exception as e:                                      # never lose the main line over the extra measurement
+            framing = {"error": repr(e)}
+
     if rank == 0:
         # per-kernel figures (HIP events on the engine's stream around every launch)
         kernels = []
@@ -619,7 +665,7 @@ def run_rank(args, world, rank, local_rank):
             "metric": ("audio-seconds/sec prosody+align throughput, 16 kHz French" if wdims
                        else "audio-seconds/sec prosody throughput (no alignment leg), 16 kHz French"),
             "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_spread": spread,
+            "n_gpus": world, "dist_backend": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_spread": spread,
             "timing_note": ("the timed region carries the per-kernel HIP event pairs of the profile (about 0.5 % of a step: --no-profile runs without them)"
                             if not args.no_profile else "no per-kernel events in the timed region"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": f"{eng.whisper_operands} (MFMA legs) + f64 (F0 / LUFS)" if wdims else "f64",
@@ -627,7 +673,7 @@ def run_rank(args, world, rank, local_rank):
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, " + what,
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
                        "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)"},
-            "roofline": roofline, "mfma_floor": floor, "gemm_shapes": gemm_shapes, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
+            "roofline": roofline, "framing_hbm": framing, "alignment_path_steps_per_step": (path_steps[-1] if path_steps else None), "mfma_floor": floor, "gemm_shapes": gemm_shapes, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
             "streamed_value": streamed, "transcribe": transcribe, "medium": medium, "device": info["name"], "host_cores": os.cpu_count(),
         }))
     eng.close()

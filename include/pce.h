@@ -246,7 +246,7 @@ int pce_whisper_load(pce_ctx *ctx, const pce_whisper_dims *dims, const float *we
 int pce_whisper_encode_run(pce_ctx *ctx);
 /* Self-test of the GEMM kernel the encoder's projections run on (persistent 256 x 256 tiles, csrc/pce_gemm256.inc) on host arrays of bf16 bit
  * patterns: C = epilogue(A[M][K] B[N][K]^T + bias).  epilogue 0: bias; 1: bias + exact GELU; 2: bias, written transposed per clip
- * (rows_per_clip rows each, key axis padded to vt_sp): out[(clip N + n) vt_sp + t].  N % 256 == 0, K % 64 == 0, M >= 2048. */
+ * (rows_per_clip rows each, key axis padded to vt_sp): out[(clip N + n) vt_sp + t].  N % 256 == 0, K % 64 == 0. */
 int pce_selftest_gemm(pce_ctx *ctx, const uint16_t *A, const uint16_t *B, const float *bias, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                       int32_t rows_per_clip, int32_t vt_sp, uint16_t *out);
 /* Self-test of the attention kernel (64-wide heads; csrc/pce_whisper.hip k_attention_lean) on host arrays of bf16 bit patterns: clips x
@@ -280,6 +280,14 @@ int pce_whisper_align_run(pce_ctx *ctx, const int32_t *tokens, const int32_t *to
 int pce_whisper_align_shape(pce_ctx *ctx, int32_t clip, int32_t *n_rows, int32_t *n_cols);
 /* path arrays hold up to n_rows + n_cols entries; cost (nullable) is the [n_rows][n_cols] fp64 DTW input */
 int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32_t *time_idx, int32_t *path_len, double *cost);
+/* Every clip's path of the last pce_whisper_align_run at once, asynchronously (the form a batch pipeline uses: what
+ * whisper_timestamped hands back per segment, Code/Aligners/use_whisper_timestamped.py:163, for all utterances of the batch).
+ * _enqueue queues the device-to-host copies behind the alignment on the context's stream into pinned staging memory and returns at
+ * once (*n_clips, *path_stride = max rows + max columns of the batch: the row pitch of the index arrays); _wait blocks on those
+ * copies only and writes path_len[n_clips] and the first path_len[i] entries of text_idx / time_idx [n_clips][path_stride] (either may
+ * be NULL).  slot is 0 or 1 (two batches in flight).  The same indices as pce_whisper_align_fetch clip by clip. */
+int pce_whisper_align_paths_enqueue(pce_ctx *ctx, int32_t slot, int32_t *n_clips, int32_t *path_stride);
+int pce_whisper_align_paths_wait(pce_ctx *ctx, int32_t slot, int32_t *path_len, int32_t *text_idx, int32_t *time_idx);
 
 /* ---- R8: free-running decoding, one step -------------------------------------
  * openai-whisper decoding.py at temperature 0 (a default DecodingTask with a GreedyDecoder, what whisper_timestamped's
@@ -365,6 +373,16 @@ int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32
 int pce_nw_align(pce_ctx *ctx, const int32_t *a_ids, const int64_t *a_off, const int32_t *b_ids, const int64_t *b_off, int32_t batch,
                  int32_t match, int32_t mismatch, int32_t gap, int32_t *out_i, int32_t *out_j, int32_t *out_len);
 
+/* ---- batched Levenshtein distance --------------------------
+ * Replaces levenshtein_distance (Code/Aligners/levenshtein_dist_align_txtgrids.py:43-70) for a batch of string pairs.  Pair b
+ * compares a_chars[a_off[b] .. a_off[b+1]) with b_chars[b_off[b] .. b_off[b+1]); the characters are Unicode code points (what a
+ * Python str iterates over).  Unit insertion / deletion / substitution costs; out_dist[b] = the distance (len of the other string
+ * when one is empty, :57-58).  Integer arithmetic: identical distances; no length limit.  The caller of the reference's function,
+ * main()'s merge loop (:98-158), clamps its cursors (`min(i + 1, n1 - 1)`, :113) under `while i < n1 and j < n2` and therefore
+ * never terminates: it has no output to reproduce and is not part of this interface. */
+int pce_levenshtein(pce_ctx *ctx, const uint32_t *a_chars, const int64_t *a_off, const uint32_t *b_chars, const int64_t *b_off,
+                    int32_t batch, int32_t *out_dist);
+
 /* ---- break-prediction token classifier --------------------
  * Forward pass of transformers.BertForTokenClassification, the model Code/baseline_models/pause_bert.py:127-132 trains
  * (bert-base-multilingual-uncased, num_labels = 2, MAX_LENGTH = 128; the reference has training code only: this is the
@@ -404,7 +422,7 @@ enum pce_kernel_id {
      * ("k_gemm_flat:<shape>"; PCE_K_GEMM_FLAT keeps the launches no shape is named for) */
     PCE_K_ADD_LAYERNORM, PCE_K_STFT_RAW, PCE_K_LOGMEL_NORM, PCE_K_ATTENTION_LEAN,
     PCE_K_GEMM_FLAT_QKV, PCE_K_GEMM_FLAT_OUT, PCE_K_GEMM_FLAT_FC1, PCE_K_GEMM_FLAT_FC2, PCE_K_GEMM_FLAT_XKV,
-    PCE_K_DECODE_LOOP, PCE_K_CROSS_ATTN1, PCE_K_GEMM_SKINNY, PCE_K_COUNT
+    PCE_K_DECODE_LOOP, PCE_K_CROSS_ATTN1, PCE_K_GEMM_SKINNY, PCE_K_LEVENSHTEIN, PCE_K_COUNT
 };
 int pce_profile_enable(pce_ctx *ctx, int on);
 int pce_profile_reset(pce_ctx *ctx);

@@ -445,3 +445,27 @@ def frame_energy_db(pcm_i16: np.ndarray, window: int, requantize: bool = False) 
         out.append(20.0 * np.log10(max(np.sqrt(np.mean(seg ** 2)), 1e-10)))
     return np.array(out)
 
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Levenshtein distance (legacy aligner, Code/Aligners/levenshtein_dist_align_txtgrids.py:43-70).  PINNED: golden G9
+# (tests/golden/levenshtein.json) holds the reference function's own outputs.
+# ----------------------------------------------------------------------------------------------------------------------------
+def levenshtein(s1: str, s2: str) -> int:
+    """The reference's two-row recurrence over Python characters: swap so that s2 is the shorter (:54-55), len(s1) when s2 is empty
+    (:57-58), then per character of s1 a new row ``min(previous[j + 1] + 1, current[j] + 1, previous[j] + (c1 != c2))`` (:62-68).
+    The sequential ``current[j] + 1`` term is resolved with a running minimum (numpy), which is the same integer arithmetic."""
+    if len(s1) < len(s2):
+        s1, s2 = s2, s1
+    if len(s2) == 0:
+        return len(s1)
+    b = np.frombuffer(s2.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+    prev = np.arange(len(s2) + 1, dtype=np.int64)
+    idx = np.arange(len(s2) + 1, dtype=np.int64)
+    for i, c1 in enumerate(np.frombuffer(s1.encode("utf-32-le", "surrogatepass"), dtype=np.uint32)):
+        cand = np.empty(len(s2) + 1, dtype=np.int64)
+        cand[0] = i + 1
+        cand[1:] = np.minimum(prev[1:] + 1, prev[:-1] + (b != c1))
+        # current[j] = min(cand[j], current[j - 1] + 1)  ==  min over k <= j of cand[k] + (j - k)
+        prev = np.minimum.accumulate(cand - idx) + idx
+    return int(prev[-1])

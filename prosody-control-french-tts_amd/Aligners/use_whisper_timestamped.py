@@ -28,6 +28,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from .. import hostrules as H
+from .. import shard
 from ..engine import ProsodyEngine, get_default_engine
 from ..tagger import FORBIDDEN_POS, TablePosTagger
 from ..textgrid_io import IntervalTier, TextGrid, read_textgrid, words_to_textgrid, write_textgrid  # noqa: F401  (re-exported)
@@ -121,7 +122,7 @@ class WhisperTranscriber:
         if self._engine is None:
             dev = str(self.device)
             # "cuda:3" names the device; a bare "cuda" under a one-process-per-GPU launcher is this rank's own GPU
-            self._engine = get_default_engine(int(dev.split(":")[1]) if ":" in dev else int(os.environ.get("LOCAL_RANK", "0")))
+            self._engine = get_default_engine(int(dev.split(":")[1]) if ":" in dev else shard.local_device())
         return self._engine
 
     def load_model(self) -> None:

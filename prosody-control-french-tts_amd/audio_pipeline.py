@@ -309,10 +309,10 @@ class AudioPipeline:
         self.whisper_device = cfg.get("whisper_device", "cuda")
         self.whisper_model = cfg.get("whisper_model", "turbo")
         self.settings = ProsodySettings.from_config(cfg.get("prosody_settings", {}))
-        import os
+        from . import shard
         # "cuda:3" names the device; a bare "cuda" under a one-process-per-GPU launcher means this rank's own GPU (LOCAL_RANK)
         self.device_index = (int(str(self.whisper_device).split(":")[1]) if ":" in str(self.whisper_device)
-                             else int(os.environ.get("LOCAL_RANK", "0")))
+                             else shard.local_device())
         self._engine, self._nlp, self._refine_set = engine, nlp, False
         self.results_dir.mkdir(parents=True, exist_ok=True)
         wanted = cfg.get("steps_to_run") or STEP_NAMES
@@ -328,8 +328,12 @@ class AudioPipeline:
         if self._engine is None:
             from .engine import get_default_engine
             self._engine = get_default_engine(self.device_index)             # ONE context per process: the aligner's steps use the same one
-        if self.cfg.get("pitch_refine") and not self._refine_set:            # additive key: "seeded" (default) | "praat" (Praat's own iterates)
-            self._engine.pitch_set_refine(self.cfg["pitch_refine"]); self._refine_set = True
+        if not self._refine_set:
+            # additive key: "seeded" (default) | "praat" (Praat's own iterates).  The context is shared by every pipeline of the process, so
+            # the mode is set by every pipeline, default included: a voice without the key does not inherit the previous voice's choice
+            if hasattr(self._engine, "pitch_set_refine"):
+                self._engine.pitch_set_refine(self.cfg.get("pitch_refine") or "seeded")
+            self._refine_set = True
         return self._engine
 
     # ------------------------------------------------------------------ the hot step
@@ -605,22 +609,16 @@ def run_all(cfg, base=None):
 
 
 def main(argv=None):
-    """``python -m prosody_control_french_tts_amd.audio_pipeline [config.yaml]``; initialises torch.distributed (RCCL) when started by
-    a launcher that sets WORLD_SIZE > 1."""
-    import os
+    """``python -m prosody_control_french_tts_amd.audio_pipeline [config.yaml]``; initialises torch.distributed (RCCL; gloo with
+    ``PCE_DIST_BACKEND=gloo``, see ``shard.init_from_env``) when started by a launcher that sets WORLD_SIZE > 1."""
     import yaml
+    from . import shard
     argv = sys.argv[1:] if argv is None else argv
     path = Path(argv[0]) if argv else Path("config.yaml")
     with open(path, encoding="utf-8") as f:
         cfg = yaml.safe_load(f)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    _, world, _ = shard.init_from_env()
     failed = run_all(cfg, base=path.resolve().parent)
     if world > 1:
         import torch.distributed as dist

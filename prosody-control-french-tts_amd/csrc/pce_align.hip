@@ -137,6 +137,79 @@ __global__ __launch_bounds__(DTW_MAXN) void k_nw(const int *__restrict__ a_ids, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Batched Levenshtein distance between words (legacy aligner, Code/Aligners/levenshtein_dist_align_txtgrids.py:43-70):
+// previous_row / current_row recurrence, unit costs, min(insertion, deletion, substitution) over Python characters (= Unicode code
+// points, here uint32).  Integer arithmetic: the distance is exactly the reference's.  The distance is symmetric, so the shorter
+// string takes the rows (the reference's swap at :54-55 has the same effect on its loop nest and none on the value).
+//
+// One WAVE per pair (four pairs per workgroup): lane = row of a 64-row stripe, the anti-diagonals sweep the stripe, and everything a
+// cell needs from its neighbours travels by DPP row shifts -- the cell above came from lane - 1 one step ago, the diagonal one is what
+// that shift delivered the step before, the column's character is a shift register fed at lane 0.  No LDS, no barrier.  Words fit one
+// stripe; longer strings take ceil(rows / 64) stripes, the last row of a stripe handed to the next through a global row buffer
+// (ping-pong, written and read in coalesced 64-element chunks, one device-scope fence per stripe).  No length limit.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_levenshtein(const unsigned *__restrict__ a_chars, const long long *__restrict__ a_off,
+                                                     const unsigned *__restrict__ b_chars, const long long *__restrict__ b_off, int batch,
+                                                     int *__restrict__ rows, const long long *__restrict__ rows_off, int *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, pair = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar loop control)
+    if (pair >= batch) return;
+    int N = (int)(a_off[pair + 1] - a_off[pair]), M = (int)(b_off[pair + 1] - b_off[pair]);
+    const unsigned *A = a_chars + a_off[pair], *B = b_chars + b_off[pair];
+    if (N > M) { const unsigned *t = A; A = B; B = t; const int n = N; N = M; M = n; }       // rows = the shorter string
+    if (N == 0) { if (lane == 0) out[pair] = M; return; }                                      // (:57-58)
+    int *top = rows + rows_off[pair], *bot = top + (M + 1);                                    // only touched when N > 64
+    const int n_stripes = (N + 63) >> 6;
+    for (int s = 0; s < n_stripes; s++) {
+        const int r0 = s << 6, R = min(64, N - r0), last = R - 1;
+        const bool more = s + 1 < n_stripes;
+        const unsigned my_a = lane < R ? A[r0 + lane] : 0u;
+        int cur = r0 + lane + 1;                           // score[r][0] of this lane's row r = r0 + lane + 1
+        int up = r0 + lane;                                // score[r - 1][0]
+        unsigned bch = 0u;
+        // 64-column chunks of the column characters and of the row above the stripe, fetched one chunk ahead
+        unsigned chB = lane < M ? B[lane] : 0u, nxB = 0u;
+        int chT = s == 0 ? lane + 1 : (lane + 1 <= M ? top[lane + 1] : 0), nxT = 0;
+        int botc = r0 + R;                                 // chunk of the stripe's last row being collected; element 0 = score[r0 + R][0]
+        const int steps = M + R - 1;
+        for (int t = 0; t < steps; t++) {
+            const int k = t & 63;
+            if (k == 0) {
+                if (t) { chB = nxB; chT = nxT; }
+                const int c1 = t + 64 + lane;              // next chunk: B[c1], top[c1 + 1]
+                nxB = c1 < M ? B[c1] : 0u;
+                nxT = s == 0 ? c1 + 1 : (c1 + 1 <= M ? top[c1 + 1] : 0);
+            }
+            const unsigned b_in = (unsigned)__builtin_amdgcn_readlane((int)chB, k);            // B[t]
+            const int top_in = __builtin_amdgcn_readlane(chT, k);                               // score[r0][t + 1]
+            const int upn_s = __builtin_amdgcn_update_dpp(0, cur, 0x138, 0xF, 0xF, true);                   // wave_shr:1 = the lane above's value
+            const unsigned bch_s = (unsigned)__builtin_amdgcn_update_dpp(0, (int)bch, 0x138, 0xF, 0xF, true);
+            const int upn = lane == 0 ? top_in : upn_s;
+            bch = lane == 0 ? b_in : bch_s;
+            const int c = t - lane + 1;                    // this lane's column at this step
+            if (lane < R && c >= 1 && c <= M) {
+                const int sub = up + (my_a != bch ? 1 : 0), ins = upn + 1, del = cur + 1;      // (:64-67)
+                cur = min(min(ins, del), sub);
+                up = upn;
+            }
+            if (more) {
+                const int cb = t - last + 1;               // the column the stripe's last row has just finished
+                if (cb >= 1) {
+                    const int v = __builtin_amdgcn_readlane(cur, last);
+                    if (lane == (cb & 63)) botc = v;
+                    if ((cb & 63) == 63 || cb == M) {
+                        const int base = cb & ~63;
+                        if (lane <= (cb & 63)) bot[base + lane] = botc;
+                    }
+                }
+            }
+        }
+        if (!more) { if (lane == last) out[pair] = cur; }
+        else { __threadfence(); int *x = top; top = bot; bot = x; }
+    }
+}
+
 } // namespace
 
 // device-resident batch (used by the Whisper alignment path): all pointers are device pointers
@@ -222,6 +295,45 @@ int pce_nw_align(pce_ctx *c, const int32_t *a_ids, const int64_t *a_off, const i
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
     for (DevBuf *x : {&da, &db, &dao, &dbo, &dtr, &dtro, &doi, &doj, &doo, &dol}) x->release();
+    return PCE_OK;
+}
+
+int pce_levenshtein(pce_ctx *c, const uint32_t *a_chars, const int64_t *a_off, const uint32_t *b_chars, const int64_t *b_off, int32_t batch,
+                    int32_t *out_dist)
+{
+    if (!c || !a_off || !b_off || !out_dist || batch <= 0) return PCE_E_INVALID;
+    PCE_HIP(c, hipSetDevice(c->device));
+    if (a_off[0] != 0 || b_off[0] != 0) return pce_fail(c, PCE_E_INVALID, "pce_levenshtein: offsets must start at 0");
+    std::vector<long long> ro((size_t)batch + 1, 0);
+    for (int32_t b = 0; b < batch; b++) {
+        const int64_t n = a_off[b + 1] - a_off[b], m = b_off[b + 1] - b_off[b];
+        if (n < 0 || m < 0) return pce_fail(c, PCE_E_INVALID, "pce_levenshtein: offsets of pair %d decrease", b);
+        if (n > 0x3fffffff || m > 0x3fffffff) return pce_fail(c, PCE_E_LIMIT, "pce_levenshtein: pair %d is longer than 2^30 characters", b);
+        const int64_t shorter = n < m ? n : m, longer = n < m ? m : n;
+        ro[(size_t)b + 1] = ro[(size_t)b] + (shorter > 64 ? 2 * (longer + 1) : 0);          // stripe hand-over rows (ping-pong)
+    }
+    const size_t na = (size_t)a_off[batch], nb = (size_t)b_off[batch];
+    if ((na && !a_chars) || (nb && !b_chars)) return PCE_E_INVALID;
+    DevBuf da, db, dao, dbo, dro, drows, dout;
+    PCE_HIP(c, da.reserve(sizeof(unsigned) * (na + 1))); PCE_HIP(c, db.reserve(sizeof(unsigned) * (nb + 1)));
+    PCE_HIP(c, dao.reserve(sizeof(long long) * ((size_t)batch + 1))); PCE_HIP(c, dbo.reserve(sizeof(long long) * ((size_t)batch + 1)));
+    PCE_HIP(c, dro.reserve(sizeof(long long) * ((size_t)batch + 1))); PCE_HIP(c, drows.reserve(sizeof(int) * ((size_t)ro[(size_t)batch] + 1)));
+    PCE_HIP(c, dout.reserve(sizeof(int) * (size_t)batch));
+    if (na) PCE_HIP(c, hipMemcpyAsync(da.p, a_chars, sizeof(unsigned) * na, hipMemcpyHostToDevice, c->stream));
+    if (nb) PCE_HIP(c, hipMemcpyAsync(db.p, b_chars, sizeof(unsigned) * nb, hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dao.p, a_off, sizeof(long long) * ((size_t)batch + 1), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dbo.p, b_off, sizeof(long long) * ((size_t)batch + 1), hipMemcpyHostToDevice, c->stream));
+    PCE_HIP(c, hipMemcpyAsync(dro.p, ro.data(), sizeof(long long) * ro.size(), hipMemcpyHostToDevice, c->stream));
+    {
+        KernelTimer t(c, PCE_K_LEVENSHTEIN);
+        hipLaunchKernelGGL(k_levenshtein, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, c->stream, da.as<unsigned>(), dao.as<long long>(),
+                           db.as<unsigned>(), dbo.as<long long>(), batch, drows.as<int>(), dro.as<long long>(), dout.as<int>());
+    }
+    PCE_HIP(c, hipGetLastError());
+    PCE_HIP(c, hipMemcpyAsync(out_dist, dout.p, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
+    PCE_HIP(c, hipStreamSynchronize(c->stream));
+    pce_profile_collect(c);
+    for (DevBuf *x : {&da, &db, &dao, &dbo, &dro, &drows, &dout}) x->release();
     return PCE_OK;
 }
 

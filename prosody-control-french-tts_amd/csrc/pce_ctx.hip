@@ -350,7 +350,7 @@ const char *pce_kernel_name(int id)
         "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat",
         "k_add_layernorm", "k_stft_raw", "k_logmel_norm", "k_attention_lean",
         "k_gemm_flat:qkv", "k_gemm_flat:out", "k_gemm_flat:fc1", "k_gemm_flat:fc2", "k_gemm_flat:xkv",
-        "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny"};
+        "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny", "k_levenshtein"};
     return (id >= 0 && id < PCE_K_COUNT) ? names[id] : "?";
 }
 

@@ -76,6 +76,7 @@ constexpr double LOG2E_D = 1.4426950408889634073599246810018921374266;
 constexpr int PI_WPB = 4;                 // waves per block in k_pitch_frames
 constexpr int PI_FPB = 4;                 // frames per work item (one per wave measured fastest: silent frames exit early)
 constexpr int PI_MAXC = 16;               // candidates per frame the kernels can hold
+constexpr int PI_MEDIAN_LDS = 16384;      // voiced F0 values k_pitch_median sorts in LDS (128 KB)
 constexpr int RF_LISTS = 256;             // independent candidate lists (one hot counter would serialise in L2)
 constexpr int RF_CSTRIDE = 32;            // counters on their own 128-byte lines             // frames staged per LDS tile in k_pitch_path
 
@@ -1331,6 +1332,7 @@ __global__ __launch_bounds__(256) void k_pitch_median(const PiSlice *__restrict_
         if (tid == 0) { out[blockIdx.x].n_voiced = 0; out[blockIdx.x].median = 0.0; out[blockIdx.x].mean_log = 0.0; }
         return;
     }
+    if (s.n_frames > npow2) return;                       // longer than the LDS sort holds: k_pitch_median_long's
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     const double *f = f0 + s.frame_off;
@@ -1366,6 +1368,74 @@ __global__ __launch_bounds__(256) void k_pitch_median(const PiSlice *__restrict_
         if (nv == 0) { o.median = 0.0; o.mean_log = 0.0; }
         else {
             o.median = (nv & 1) ? sbuf[nv / 2] : (sbuf[nv / 2 - 1] + sbuf[nv / 2]) / 2.0;
+            o.mean_log = (((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]) / (double)nv;
+        }
+        out[blockIdx.x] = o;
+    }
+}
+
+// The same summary for a slice of any length (get_median_pitch takes a whole recording, Code/audioPipeline.py:326-335: the reference has no
+// limit): the k-th smallest voiced F0 by radix selection on the bit patterns (positive doubles order as their 64-bit integers), eight
+// 256-bin passes over the slice's F0 track in global memory per selected rank.  Exact: the median is np.median's (the middle element, or
+// the mean of the two middle ones); the log sum adds in the order k_pitch_median adds (per thread by stride 256, then the same tree).
+// One workgroup per slice; slices the LDS sort holds return at once.
+__global__ __launch_bounds__(256) void k_pitch_median_long(const PiSlice *__restrict__ slices, const double *__restrict__ f0, int lds_limit,
+                                                          PiSummaryDev *__restrict__ out)
+{
+    __shared__ int hist[256];
+    __shared__ int s_cnt;
+    __shared__ double s_red[4];
+    __shared__ unsigned long long s_prefix;
+    __shared__ long long s_k;
+    const PiSlice s = slices[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (s.status != PCE_SLICE_OK || s.n_frames <= lds_limit) return;
+    const double *f = f0 + s.frame_off;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    double lsum = 0.0; int mine = 0;
+    for (int i = tid; i < s.n_frames; i += 256) {
+        const double v = f[i];
+        if (v > 0.0) { mine++; lsum += log(v); }
+    }
+    atomicAdd(&s_cnt, mine);
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = lsum;
+    __syncthreads();
+    const int nv = s_cnt;
+    double sel[2] = {0.0, 0.0};
+    const int want = nv == 0 ? 0 : ((nv & 1) ? 1 : 2);
+    for (int q = 0; q < want; q++) {
+        if (tid == 0) { s_prefix = 0ull; s_k = (nv & 1) ? nv / 2 : nv / 2 - 1 + q; }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            for (int i = tid; i < s.n_frames; i += 256) {
+                const double v = f[i];
+                if (v > 0.0) {
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+                    if (shift == 56 || (b >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((b >> shift) & 255ull)], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                long long k = s_k; int bin = 0;
+                while (bin < 255 && k >= hist[bin]) { k -= hist[bin]; bin++; }
+                s_k = k; s_prefix = prefix | ((unsigned long long)bin << shift);
+            }
+            __syncthreads();
+        }
+        sel[q] = __longlong_as_double((long long)s_prefix);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        PiSummaryDev o;
+        o.n_voiced = nv;
+        if (nv == 0) { o.median = 0.0; o.mean_log = 0.0; }
+        else {
+            o.median = (nv & 1) ? sel[0] : (sel[0] + sel[1]) / 2.0;
             o.mean_log = (((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]) / (double)nv;
         }
         out[blockIdx.x] = o;
@@ -1536,9 +1606,9 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
             if (nf > max_frames) max_frames = nf;
             for (int64_t f = 0; f < nf; f += P.fpb) work.push_back({i, (int32_t)f});
         }
-        int np2 = 1; while (np2 < max_frames) np2 <<= 1;
-        if ((size_t)np2 * sizeof(double) > 128 * 1024) return pce_fail(c, PCE_E_LIMIT, "slice with %lld frames exceeds the %d-frame median limit", (long long)max_frames, 16384);
-        c->pi_np2 = np2;
+        int np2 = 1; while (np2 < max_frames && np2 < PI_MEDIAN_LDS) np2 <<= 1;
+        c->pi_np2 = np2;                                       // the in-LDS sort's size; longer slices (a recording of more than 82 s at floor 150) go to k_pitch_median_long
+        c->pi_long_slices = max_frames > PI_MEDIAN_LDS;
         c->pi_n_work = (int64_t)work.size();
         PCE_HIP(c, c->pi_meta.reserve(sizeof(PiSlice) * hs.size()));
         PCE_HIP(c, c->pi_work.reserve(sizeof(PiWork) * (work.size() + 1)));
@@ -1671,6 +1741,9 @@ int pce_pitch_run(pce_ctx *c, const pce_pitch_params *p, const pce_slice *slices
         KernelTimer t(c, PCE_K_PITCH_MEDIAN, tail);
         hipLaunchKernelGGL(k_pitch_median, dim3((unsigned)n), dim3(256), lds, tail, c->pi_meta.as<PiSlice>(),
                            c->pi_f0.as<double>(), c->pi_np2, c->pi_summary.as<PiSummaryDev>());
+        if (c->pi_long_slices)
+            hipLaunchKernelGGL(k_pitch_median_long, dim3((unsigned)n), dim3(256), 0, tail, c->pi_meta.as<PiSlice>(), c->pi_f0.as<double>(), c->pi_np2,
+                               c->pi_summary.as<PiSummaryDev>());
     }
     { int rc2 = pce_side_end(c, pce_ctx::SIDE_TAIL, tail); if (rc2) return rc2; }
     PCE_HIP(c, hipGetLastError());

@@ -18,6 +18,8 @@ PCE_BOTH(int, pce_whisper_decoder_load, (pce_ctx *, const pce_whisper_text_dims 
 PCE_BOTH(int, pce_whisper_align_run, (pce_ctx *, const int32_t *, const int32_t *, const int32_t *, int32_t, const uint8_t *, int32_t, float))
 PCE_BOTH(int, pce_whisper_align_fetch, (pce_ctx *, int32_t, int32_t *, int32_t *, int32_t *, double *))
 PCE_BOTH(int, pce_whisper_align_shape, (pce_ctx *, int32_t, int32_t *, int32_t *))
+PCE_BOTH(int, pce_whisper_align_paths_enqueue, (pce_ctx *, int32_t, int32_t *, int32_t *))
+PCE_BOTH(int, pce_whisper_align_paths_wait, (pce_ctx *, int32_t, int32_t *, int32_t *, int32_t *))
 PCE_BOTH(int, pce_whisper_decode_step, (pce_ctx *, const int32_t *, const int32_t *, int32_t, const pce_whisper_decode_rules *, const uint8_t *, int32_t *, float *))
 PCE_BOTH(int, pce_whisper_decode_step_ex, (pce_ctx *, const int32_t *, const int32_t *, const pce_whisper_decode_rules *, const uint8_t *, const pce_whisper_decode_opts *, int32_t *, float *, float *))
 PCE_BOTH(int, pce_whisper_decode_loop, (pce_ctx *, const int32_t *, const int32_t *, const pce_whisper_decode_rules *, const uint8_t *, const pce_whisper_decode_opts *, int32_t, int32_t, int32_t *, float *, int32_t *, float *))
@@ -72,6 +74,11 @@ int pce_whisper_align_fetch(pce_ctx *c, int32_t clip, int32_t *text_idx, int32_t
     return PCE_FWD(pce_whisper_align_fetch, c, clip, text_idx, time_idx, path_len, cost);
 }
 int pce_whisper_align_shape(pce_ctx *c, int32_t clip, int32_t *n_rows, int32_t *n_cols) { return PCE_FWD(pce_whisper_align_shape, c, clip, n_rows, n_cols); }
+int pce_whisper_align_paths_enqueue(pce_ctx *c, int32_t slot, int32_t *n_clips, int32_t *path_stride) { return PCE_FWD(pce_whisper_align_paths_enqueue, c, slot, n_clips, path_stride); }
+int pce_whisper_align_paths_wait(pce_ctx *c, int32_t slot, int32_t *path_len, int32_t *text_idx, int32_t *time_idx)
+{
+    return PCE_FWD(pce_whisper_align_paths_wait, c, slot, path_len, text_idx, time_idx);
+}
 int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, int32_t sample_begin, const pce_whisper_decode_rules *rules,
                             const uint8_t *vocab_mask, int32_t *next_tokens, float *next_logprobs)
 {

@@ -22,7 +22,9 @@ class PceError(RuntimeError):
 
 
 def native_library_path() -> str:
-    return _LIB_PATH
+    """The library this process binds: ``libpce.so`` beside this file, or the file ``PCE_LIBRARY`` names (laboratory builds are
+    selected this way -- ``tools/ab_*.sh`` -- instead of being copied over the product's library)."""
+    return os.environ.get("PCE_LIBRARY") or _LIB_PATH
 
 
 def build_native(force: bool = False) -> str:
@@ -99,7 +101,7 @@ KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs
               "k_gemm_bf16", "k_gemm_wide", "k_attention", "k_layernorm", "k_gemm_flat",
               "k_add_layernorm", "k_stft_raw", "k_logmel_norm", "k_attention_lean",
               "k_gemm_flat:qkv", "k_gemm_flat:out", "k_gemm_flat:fc1", "k_gemm_flat:fc2", "k_gemm_flat:xkv",
-              "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny"]     # = pce_kernel_name(id) for every id (tests/test_abi_and_shard.py)
+              "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny", "k_levenshtein"]     # = pce_kernel_name(id) for every id (tests/test_abi_and_shard.py)
 
 # every symbol include/pce.h declares
 EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
@@ -109,17 +111,18 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_set_refine", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
+           "pce_dtw", "pce_nw_align", "pce_levenshtein", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_align_paths_enqueue", "pce_whisper_align_paths_wait", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_selftest_attention", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
 
 
 def load_library() -> C.CDLL:
-    if not os.path.exists(_LIB_PATH):
-        raise PceError(f"{_LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+    path = native_library_path()
+    if not os.path.exists(path):
+        raise PceError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                        "this engine has no CPU fallback")
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.pce_create.argtypes = [C.c_int, vp, C.c_char_p, C.c_size_t]; lib.pce_create.restype = vp
     lib.pce_destroy.argtypes = [vp]; lib.pce_destroy.restype = None
@@ -147,6 +150,7 @@ def load_library() -> C.CDLL:
     lib.pce_pitch_fetch.argtypes = [vp, vp, vp, vp]
     lib.pce_stats_enqueue.argtypes = [vp, i32]
     lib.pce_nw_align.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.pce_levenshtein.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.pce_stats_wait.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pce_stft_db_run.argtypes = [vp, i32, i32]
     lib.pce_stft_db_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -164,6 +168,8 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_get_operands.argtypes = [vp]
     lib.pce_whisper_decode_loop.argtypes = [vp, vp, vp, C.POINTER(WhisperDecodeRules), vp, C.POINTER(WhisperDecodeOpts), i32, i32, vp, vp, vp, vp]
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
+    lib.pce_whisper_align_paths_enqueue.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.pce_whisper_align_paths_wait.argtypes = [vp, i32, vp, vp, vp]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
     lib.pce_bert_fetch.argtypes = [vp, i32, vp, vp]
@@ -207,6 +213,7 @@ class ProsodyEngine:
         self._ctx = self._lib.pce_create(int(device), C.c_void_p(stream) if stream else None, err, len(err))
         if not self._ctx:
             raise PceError(f"pce_create failed: {err.value.decode(errors='replace')}")
+        self.device = int(device)
         self.rate = 0
         self.clip_lengths = np.zeros(0, dtype=np.int64)
         self._keep = []
@@ -499,6 +506,19 @@ class ProsodyEngine:
         self._check(self._lib.pce_whisper_align_run(self._ctx, toks.ctypes.data, off.ctypes.data, nf.ctypes.data, int(sot_len),
                                                     hm.ctypes.data if hm is not None else None, int(medfilt_width), float(qk_scale)))
 
+    def whisper_align_paths_enqueue(self, slot: int = 0):
+        """Queue the device-to-host copies of every clip's DTW path of the last ``whisper_align_run`` (pinned staging, returns at once)."""
+        n = C.c_int32(); stride = C.c_int32()
+        self._check(self._lib.pce_whisper_align_paths_enqueue(self._ctx, int(slot), C.byref(n), C.byref(stride)))
+        self._al_slot = getattr(self, "_al_slot", {}); self._al_slot[int(slot)] = (n.value, stride.value)
+
+    def whisper_align_paths_wait(self, slot: int = 0):
+        """-> (path_len[n], text_idx[n][stride], time_idx[n][stride]); row i holds path_len[i] steps."""
+        n, stride = self._al_slot[int(slot)]
+        pl = np.zeros(n, dtype=np.int32); ti = np.zeros((n, stride), dtype=np.int32); tj = np.zeros((n, stride), dtype=np.int32)
+        self._check(self._lib.pce_whisper_align_paths_wait(self._ctx, int(slot), pl.ctypes.data, ti.ctypes.data, tj.ctypes.data))
+        return pl, ti, tj
+
     def whisper_align(self, token_lists, num_frames, sot_len: int, head_mask=None, medfilt_width: int = 7, qk_scale: float = 1.0,
                       want_cost: bool = False):
         """Forced alignment of the given token sequences (one per clip, specials included) against the encoded audio.
@@ -643,6 +663,22 @@ class ProsodyEngine:
         self.bert_run(token_lists)
         return [self.bert_fetch(i) for i in range(len(token_lists))]
 
+    def levenshtein(self, pairs):
+        """Levenshtein distances of a batch of string pairs in one launch (``pce_levenshtein``): ``pairs`` = [(s1, s2), ...] of ``str``
+        -> int32 array.  Characters are code points, as ``for c in s`` of Code/Aligners/levenshtein_dist_align_txtgrids.py:62."""
+        if not len(pairs):
+            return np.zeros(0, dtype=np.int32)
+
+        def pack(strings):
+            cps = [np.frombuffer(s.encode("utf-32-le", "surrogatepass"), dtype=np.uint32) for s in strings]
+            off = np.zeros(len(cps) + 1, dtype=np.int64); np.cumsum([len(x) for x in cps], out=off[1:])
+            return np.ascontiguousarray(np.concatenate(cps + [np.zeros(0, np.uint32)])), off
+        a, ao = pack([p[0] for p in pairs]); b, bo = pack([p[1] for p in pairs])
+        out = np.zeros(len(pairs), dtype=np.int32)
+        self._check(self._lib.pce_levenshtein(self._ctx, a.ctypes.data if a.size else None, ao.ctypes.data, b.ctypes.data if b.size else None,
+                                              bo.ctypes.data, len(pairs), out.ctypes.data))
+        return out
+
     def nw_align(self, pairs, match=1, mismatch=-1, gap=-1):
         """Batched Needleman-Wunsch over integer token ids: ``pairs`` = [(ids_a, ids_b), ...] ->
         [(i_idx, j_idx), ...] with -1 marking a gap (alignment order)."""
@@ -687,11 +723,16 @@ class ProsodyEngine:
 _DEFAULT_ENGINE = None
 
 
-def get_default_engine(device: int = 0) -> ProsodyEngine:
-    """Process-wide engine used by the module-level drop-in functions (``Pipeline.compute_*``)."""
+def get_default_engine(device: int = None) -> ProsodyEngine:
+    """Process-wide engine used by the module-level drop-in functions (``Pipeline.compute_*``).  ONE context per process (the
+    reference's process owns one Whisper model on one GPU, config.yaml:58): ``device=None`` takes whatever engine exists (device 0
+    when none does); naming a device other than the existing engine's is an error rather than a silent run on the wrong GPU."""
     global _DEFAULT_ENGINE
     if _DEFAULT_ENGINE is None:
-        _DEFAULT_ENGINE = ProsodyEngine(device)
+        _DEFAULT_ENGINE = ProsodyEngine(0 if device is None else device)
+    elif device is not None and getattr(_DEFAULT_ENGINE, "device", device) != device:
+        raise RuntimeError(f"this process's engine lives on device {_DEFAULT_ENGINE.device}; device {device} was asked for "
+                           "(one context per process: start one process per GPU, or close the engine first)")
     return _DEFAULT_ENGINE
 
 

@@ -38,6 +38,39 @@ def rank_world():
     return 0, 1
 
 
+def local_device() -> int:
+    """Device index of this rank under a one-process-per-GPU launcher: ``LOCAL_RANK``, unless ``PCE_RANK_DEVICE`` names the device
+    (several ranks sharing ONE GPU -- the only multi-rank form a single-GPU box can run; see :func:`init_from_env`)."""
+    import os
+    return int(os.environ.get("PCE_RANK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_from_env():
+    """Join the launcher's process group (``RANK`` / ``WORLD_SIZE`` / ``MASTER_*`` in the environment) -> (rank, world, device index).
+    Backend "nccl" (= RCCL over xGMI), one rank per GPU.  ``PCE_DIST_BACKEND=gloo`` selects gloo for the SAME code path -- the control
+    plane and the one all-gather then travel over host memory; RCCL refuses two ranks on one device, so this (with
+    ``PCE_RANK_DEVICE=0``) is how the real engine runs under more than one rank on a one-GPU box.  No process group when WORLD_SIZE
+    is absent or 1.  The reference's parallel driver is the spawn pool of Code/audioPipeline.py:1143-1150."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = local_device()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("PCE_DIST_BACKEND", "nccl")
+        if backend not in ("nccl", "gloo"):
+            raise ValueError(f"PCE_DIST_BACKEND={backend!r}: nccl or gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, dev
+
+
 class PeerFailure(RuntimeError):
     """Another rank failed in the section all ranks have just left (or flagged its block of an exchange as failed): this rank
     stops the same step, so that the next collective every rank enters is the same one."""

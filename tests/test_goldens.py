@@ -154,3 +154,51 @@ def test_g6_textgrid_text_extraction_identical():
     from prosody_control_french_tts_amd.Pipeline import utils as U
     for case in load("textgrid_text.json"):
         assert U.extract_clean_text_from_textgrid(case["content"]) == case["expected"]
+
+
+def test_g9_levenshtein_oracle_matches_the_reference_function():
+    """oracle.levenshtein against the outputs of the reference's own levenshtein_distance (Code/Aligners/levenshtein_dist_align_txtgrids.py:43-70)."""
+    g = load("levenshtein.json")
+    assert len(g["cases"]) >= 200
+    for c in g["cases"]:
+        assert O.levenshtein(c["s1"], c["s2"]) == c["distance"], (c["s1"][:40], c["s2"][:40])
+        assert O.levenshtein(c["s2"], c["s1"]) == c["distance"]
+    assert any(len(c["s1"]) < len(c["s2"]) for c in g["cases"]) and any(c["s1"] == "" or c["s2"] == "" for c in g["cases"])
+
+
+def test_levenshtein_module_host_side_without_a_gpu(tmp_path):
+    """The host side of the Levenshtein mirror (Code/Aligners/levenshtein_dist_align_txtgrids.py): interval repair of list_to_textgrid (:11-32),
+    normalize_word (:34-41), and the terminating merge driven by an engine stand-in that answers from the oracle."""
+    from prosody_control_french_tts_amd.Aligners import levenshtein_dist_align_txtgrids as LV
+    from prosody_control_french_tts_amd import textgrid_io as TG
+
+    class OracleDistances:
+        calls = 0
+        def levenshtein(self, pairs):
+            OracleDistances.calls += 1
+            return np.array([O.levenshtein(a, b) for a, b in pairs], dtype=np.int32)
+
+    tg = LV.list_to_textgrid([("b", 0.5, 0.4), ("a", 0.0, 0.6), ("c", 0.55, 1.0)])
+    assert [(round(a, 9), round(b, 9), m) for a, b, m in tg.tiers[0].intervals] == [(0.0, 0.6, "a"), (0.6, 0.61, "b"), (0.61, 1.0, "c")]
+    assert LV.normalize_word("Cœur-brisé, là!") == "coeurbrise,la" and LV.normalize_word("Peut-être?") == "peutetre"
+    # two tiers of the same sentence, one with a word split in two and a pause interval, the other with an extra pause
+    t1 = [(0.0, 0.3, "bon"), (0.3, 0.5, "jour"), (0.5, 0.6, " "), (0.6, 1.0, "le"), (1.0, 1.5, "monde")]
+    t2 = [(0.0, 0.55, "bonjour"), (0.55, 0.9, "le"), (0.9, 1.0, ""), (1.0, 1.4, "mondes")]
+    eng = OracleDistances()
+    (n1, n2), (m1, m2) = LV.merge_word_tiers([(t1, t2), (t2, t2)], eng)
+    assert [w for w, _, _ in n1] == ["bon jour", " ", "le", "mondes"] and [w for w, _, _ in n2] == ["bon jour", "le", " ", "mondes"]
+    assert n1[0][1:] == (0.0, 0.5) and n2[0][1:] == (0.0, 0.55) and n1[-1][1:] == (1.0, 1.5)
+    assert [w for w, _, _ in m1] == [w for w, _, _ in m2] == ["bonjour", "le", " ", "mondes"]
+    assert OracleDistances.calls <= 5                       # both tier pairs advance in lock-step: one batched call per step
+    # main(): files rewritten in place, transcriptions updated
+    p1, p2 = tmp_path / "a.TextGrid", tmp_path / "b.TextGrid"
+    for p, t in ((p1, t1), (p2, t2)):
+        tier = TG.IntervalTier("words")
+        for a, b, m in t:
+            tier.add(a, b, m)
+        TG.write_textgrid(TG.TextGrid([tier]), p)
+    (tmp_path / "tr1").mkdir(); (tmp_path / "tr2").mkdir()
+    LV.main(str(p1), str(p2), str(tmp_path / "tr1"), str(tmp_path / "tr2"), engine=eng)
+    assert (tmp_path / "tr1" / "a.txt").read_text(encoding="utf-8") == "bon jour le mondes"
+    assert (tmp_path / "tr2" / "b.txt").read_text(encoding="utf-8") == "bon jour le mondes"
+    assert [m for _, _, m in TG.read_textgrid(p2).tiers[0].intervals] == ["bon jour", "le", " ", "mondes"]

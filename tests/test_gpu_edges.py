@@ -347,3 +347,76 @@ def test_environment_switches_of_pce_create(engine, monkeypatch):
             # (the two kernels sum identically; the compiler schedules the inlined GELU differently in them, and a few 1e-5 of its fp16 outputs
             # round to the neighbouring value: the same tokens, log-probabilities to the last digits)
             assert got[1] == base[1] and all(np.allclose(x, y, rtol=0, atol=2e-3) for x, y in zip(got[2], base[2]))
+
+
+@pytest.mark.gpu
+def test_levenshtein_gpu_reproduces_the_reference_distances(engine):
+    """pce_levenshtein (one wave per pair, the whole batch in one launch) against golden G9 = the outputs of the reference's own
+    levenshtein_distance (Code/Aligners/levenshtein_dist_align_txtgrids.py:43-70): bit-exact, both argument orders, plus seeded random
+    pairs of every stripe count against the CPU restatement, a 5 000-character pair (79 stripes), and the merge loop on the GPU."""
+    import json, os
+    from oracle import oracle as O
+    from prosody_control_french_tts_amd.Aligners import levenshtein_dist_align_txtgrids as LV
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "levenshtein.json"), encoding="utf-8"))["cases"]
+    pairs = [(c["s1"], c["s2"]) for c in cases]
+    got = engine.levenshtein(pairs)
+    assert got.dtype == np.int32 and got.tolist() == [c["distance"] for c in cases]
+    assert engine.levenshtein([(b, a) for a, b in pairs]).tolist() == [c["distance"] for c in cases]
+    assert LV.levenshtein_distance("voilà", "voila", engine) == 1 and LV.levenshtein_distances([], engine) == []
+    rng = np.random.default_rng(11)
+    extra = []
+    for n in list(range(0, 9)) + [62, 63, 64, 65, 66, 127, 128, 129, 191, 192, 193, 320, 1000]:
+        for m in (0, 1, 5, 64, 65, 130, n):
+            for alpha in ("ab", "abcdefghéà "):
+                extra.append(("".join(rng.choice(list(alpha), n)) if n else "", "".join(rng.choice(list(alpha), m)) if m else ""))
+    got = engine.levenshtein(extra)
+    assert got.tolist() == [O.levenshtein(a, b) for a, b in extra]
+    big = "".join(rng.choice(list("abcde"), 5000)); big2 = big[:1700] + "xyz" + big[1750:4000] + big[4100:]
+    assert engine.levenshtein([(big, big2), (big2, big), (big, big)]).tolist() == [O.levenshtein(big, big2)] * 2 + [0]
+    # the (terminating) merge loop with the distances from the GPU = with the distances from the CPU restatement
+    class CpuDistances:
+        def levenshtein(self, ps):
+            return np.array([O.levenshtein(a, b) for a, b in ps], dtype=np.int32)
+    words = ["bon", "jour", "bonjour", "le", "la", "monde", "mondes", " ", "", "très", "tres", "bien", "oui", "non", "peut", "être", "peut-être"]
+    def tier(k):
+        t, out = 0.0, []
+        for _ in range(k):
+            d = float(rng.integers(5, 40)) / 100.0
+            out.append((t, t + d, str(rng.choice(words)))); t += d
+        return out
+    tiers = [(tier(int(rng.integers(1, 30))), tier(int(rng.integers(1, 30)))) for _ in range(40)]
+    assert LV.merge_word_tiers(tiers, engine) == LV.merge_word_tiers(tiers, CpuDistances())
+
+
+@pytest.mark.gpu
+def test_whole_recording_of_two_minutes_has_no_frame_limit(engine):
+    """get_median_pitch takes any recording (Code/audioPipeline.py:326-335: no length limit).  A 120 s clip = 23 997 frames at floor 150,
+    more than the in-LDS median sort holds (16 384): the slice goes to k_pitch_median_long (radix selection in global memory).  Track,
+    voiced median (np.median) and mean log against the oracle; short slices of the same batch still take the LDS kernel; odd and even
+    voiced counts both occur."""
+    from prosody_control_french_tts_amd import synth, PitchParams
+    from oracle import oracle as O
+    long_clip = np.concatenate([synth.synth_clip(900 + i, seconds=10.0) for i in range(12)])
+    short = synth.synth_clip(3, seconds=3.0)
+    engine.upload([long_clip, short], 16000)
+    from prosody_control_french_tts_amd.engine import make_slices
+    # whole long clip, the short clip, the long clip minus its first 7 ms (another voiced count: the other parity with luck, checked below)
+    sl = make_slices([0, 1, 0, 0], [0, 0, 112, 0], [len(long_clip), len(short), len(long_clip), 90 * 16000], [0.5 / 16000, 0.5 / 16000, 112.5 / 16000, 0.5 / 16000])
+    res = engine.pitch(sl, PitchParams.praat(150.0, 600.0))
+    summ, off = res["summary"], res["frame_offsets"]
+    assert off[1] - off[0] == 23997 and off[1] - off[0] > 16384
+    parities = set()
+    for k, (clip, b, e) in enumerate([(long_clip, 0, len(long_clip)), (short, 0, len(short)), (long_clip, 112, len(long_clip)), (long_clip, 0, 90 * 16000)]):
+        want = O.pitch_ac(clip[b:e] / 32768.0, 1 / 16000, float(sl[k]["x1"]), O.praat_params(150.0, 600.0))["f0"]
+        got = res["f0"][off[k]:off[k + 1]]
+        assert got.shape == want.shape and np.array_equal(got > 0, want > 0)
+        v = want > 0
+        assert np.max(np.abs(got[v] - want[v]) / want[v]) < 1e-6
+        assert summ[k]["n_voiced"] == int(v.sum())
+        # the median is an ELEMENT (or the mean of two) of the GPU's own track: exact against np.median of that track
+        assert summ[k]["median_f0"] == float(np.median(got[got > 0]))
+        assert abs(summ[k]["median_f0"] - float(np.median(want[v]))) <= 1e-6 * float(np.median(want[v]))
+        assert abs(summ[k]["mean_log_f0"] - float(np.mean(np.log(got[got > 0])))) <= 1e-12 * abs(float(np.mean(np.log(got[got > 0]))))
+        if k != 1:
+            parities.add(int(v.sum()) & 1)
+    assert parities == {0, 1}, parities

@@ -150,6 +150,18 @@ def test_forced_alignment_matches_torch(engine, clips, width, heads):
         jumps_g = got["time_indices"][np.r_[True, np.diff(got["text_indices"]) > 0]]
         jumps_w = tj[np.r_[True, np.diff(ti) > 0]]
         assert len(jumps_g) == len(jumps_w) and np.mean(np.abs(jumps_g - jumps_w) <= 1) >= 0.95          # observed: identical
+    # the batched asynchronous fetch (pce_whisper_align_paths_enqueue / _wait: what a batch pipeline and bench.py's timed step use) hands over
+    # the same indices as the clip-by-clip fetch; two slots in flight; a wait without an enqueue is an error
+    engine.whisper_align_run(toks, num_frames, sot_len)
+    engine.whisper_align_paths_enqueue(0); engine.whisper_align_paths_enqueue(1)
+    for slot in (1, 0):
+        pl, pi, pj = engine.whisper_align_paths_wait(slot)
+        assert pi.shape == pj.shape == (2, max(len(t) - sot_len - 1 for t in toks) + max(num_frames) // 2)
+        for i in range(2):
+            assert pl[i] == len(res[i]["text_indices"])
+            assert np.array_equal(pi[i, :pl[i]], res[i]["text_indices"]) and np.array_equal(pj[i, :pl[i]], res[i]["time_indices"])
+    with pytest.raises(Exception):
+        engine.whisper_align_paths_wait(0)
 
 
 def test_forced_alignment_matches_transformers_token_timestamps(engine, ops):

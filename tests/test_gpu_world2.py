@@ -1,0 +1,202 @@
+"""The REAL engine under two ranks, on the one GPU a box of this pool has.
+
+BASELINE.json configs[3] / [4] run one process per GPU over RCCL.  No multi-GPU node exists here, and RCCL refuses two ranks on one
+device, so the same code path is run with ``PCE_DIST_BACKEND=gloo PCE_RANK_DEVICE=0`` (``shard.init_from_env``): two FRESH child
+processes (never an exec from a process that has touched the GPU), each with its own ``ProsodyEngine`` context on cuda:0, the control
+plane and the one all-gather over gloo.  Everything above the backend name is what an 8-GPU launch executes: the launcher of
+``bench.py``, the rank's shard of the clips, the engine, ``shard.allgather_records``, the JSON line; ``run_all``
+(Code/audioPipeline.py:1121-1166, whose parallel driver is the spawn pool of :1143-1150) with the real steps.
+
+(a) ``bench.py --gpus 2 --workload c2 --clips 64``: ONE JSON line with ``n_gpus`` 2, and the gathered records of the 128 clips equal a
+    single-rank run's of the same 128 clips bit for bit.
+(b) ``run_all`` of tests/test_c5_chain.py with ``ProsodyEngine`` instead of the CPU stub: three voices cut from the reference's demo
+    recordings, Align+Transcribe -> Measure & Build SSML -> Final Transcribe + ``predict_breaks``; the files of a voice are text-identical
+    to a world-1 run's; a fault injected into ONE rank's engine fails that voice on BOTH ranks, the next voice runs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = dict(os.environ, PCE_DIST_BACKEND="gloo", PCE_RANK_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(kw)
+    return env
+
+
+def test_bench_two_ranks_one_device_records_equal_one_rank(tmp_path):
+    common = ["--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-clips", "0", "--streamed-steps", "0"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "64", "--dump-records", str(tmp_path / "w2.npy")] + common,
+                         env=_env(), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-3000:] + two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout[-3000:]
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["dist_backend"] == "gloo" and j2["scaling"] == "weak" and j2["cpu_baseline"] is None
+    assert j2["config"]["clips_per_gpu"] == 64 and j2["value"] > 0 and j2["roofline"] is not None
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "128", "--dump-records", str(tmp_path / "w1.npy")] + common,
+                         env=_env(), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert j1["n_gpus"] == 1 and j1["dist_backend"] is None
+    r2, r1 = np.load(tmp_path / "w2.npy"), np.load(tmp_path / "w1.npy")
+    assert r2.shape == r1.shape == (128, 7)
+    assert r2.tobytes() == r1.tobytes()                     # median F0, LUFS, rms, peak, silence ratio, duration, voiced count: bit for bit
+    assert (r1[:, 0] > 0).sum() > 100                       # (real measurements, not an empty table)
+    # value = both ranks' audio / the slower rank's time
+    assert abs(j2["value"] - 2 * 64 * 10.0 * 3 / (j2["ms_per_step"] * 3e-3)) <= 1e-6 * j2["value"]
+
+
+_WORKER = r'''
+import logging, os, sys
+import numpy as np
+rank, world, root, port, base = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+sys.path.insert(0, root)
+os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                  PCE_DIST_BACKEND="gloo", PCE_RANK_DEVICE="0")
+from pathlib import Path
+import torch.distributed as dist
+from prosody_control_french_tts_amd import audio_pipeline as AP, bert_weights as BW, engine as E, shard, tagger as T
+from tests.test_gpu_c5 import WORDS, raw_synthesis_stand_in, write_wav
+from tests.test_gpu_aligner import write_model_dir
+base = Path(base)
+logging.basicConfig(level=logging.WARNING)
+
+# three voices cut from the reference's ten demo recordings (44.1 kHz, 2.9-37.2 s)
+z = np.load(Path(root) / "tests" / "golden" / "demo_full.npz")
+rate = int(z["rate"])
+names = sorted((k for k in z.files if k != "rate"), key=T.segment_sort_key)
+VOICES = {"v1": names[:5], "bad": names[6:10], "v3": names[4:7]}            # (v3 holds the 37.2 s recording: two Whisper windows)
+
+def lay_out(b):
+    for voice, segs in VOICES.items():
+        for k, n in enumerate(segs):
+            nat = z[n]
+            write_wav(b / "Data" / "voice" / voice / "audio" / f"segment_ph{k + 1}.wav", nat, rate)
+            write_wav(b / "Data" / "voice" / f"{voice}_raw" / "audio" / f"segment_ph{k + 1}.wav", raw_synthesis_stand_in(nat, k), 16000)
+        out = np.concatenate([raw_synthesis_stand_in(z[n], k) for k, n in enumerate(segs[:2])])[: 20 * 16000]
+        write_wav(b / "Out" / "results" / voice / "OUT.wav", out, 16000)
+
+def cfg_for(voices, model_root):
+    return {"data_dir": "Data/voice", "out_dir": "Out", "azure_voice_name": "fr-FR-HenriNeural", "whisper_device": "cuda", "whisper_model": "medium",
+            "whisper_dir": str(model_root), "voice_names": voices, "multiprocessing": True, "num_processes": 5,
+            "prosody_settings": {"baseline_window": 3, "smoothing_alpha": 0.2, "max_jump_percent": 8},
+            "steps_to_run": ["Align+Transcribe", "Raw Synthesis", "Measure & Build SSML", "Final Transcribe"]}
+
+def snapshot(b, voice):
+    out = {}
+    for d in (b / "Data" / "voice" / voice, b / "Out" / "results" / voice):
+        for p in sorted(d.rglob("*")):
+            if p.is_file() and p.suffix in (".csv", ".TextGrid", ".txt", ".json"):
+                out[str(p.relative_to(b))] = p.read_text(encoding="utf-8")
+    return out
+
+model_root = base / "whisper_dir"
+if rank == 0:
+    lay_out(base)
+    write_model_dir(model_root, merges=WORDS, word_gain=3.0, eot_gain=0.3)
+r, w, dev = shard.init_from_env()
+assert (r, w, dev) == (rank, world, 0) and dist.get_backend() == "gloo"
+dist.barrier()
+
+# the product's own engine (no stub): created lazily by the first step; count this rank's uploads, inject the fault below the steps
+uploads = []
+_upload = E.ProsodyEngine.upload
+def _counting_upload(self, clips, rate_):
+    uploads.append(len(clips)); return _upload(self, clips, rate_)
+E.ProsodyEngine.upload = _counting_upload
+fail = {"on": False}
+_pitch = E.ProsodyEngine.pitch
+def _failing_pitch(self, *a, **k):
+    if fail["on"]:
+        raise RuntimeError("device lost (injected on this rank)")
+    return _pitch(self, *a, **k)
+E.ProsodyEngine.pitch = _failing_pitch
+_run = AP.AudioPipeline.run
+def _run_with_injection(self):
+    fail["on"] = (self.name == "bad" and rank == 1)
+    try:
+        return _run(self)
+    finally:
+        fail["on"] = False
+AP.AudioPipeline.run = _run_with_injection
+gathers = []
+_orig = dist.all_gather_into_tensor
+def _counting(*a, **k):
+    gathers.append(1); return _orig(*a, **k)
+dist.all_gather_into_tensor = _counting
+
+failed = AP.run_all(cfg_for(list(VOICES), model_root), base=base)
+assert failed == ["bad"], (rank, failed)                                   # the SAME verdict on both ranks, nobody hung in a collective
+assert len(gathers) == 3, gathers                                          # one exchange per voice's measure step
+eng = E.get_default_engine()
+assert type(eng) is E.ProsodyEngine and eng.device == 0 and eng.device_info()["compute_units"] == 256
+n_mine = {v: (lambda lo_hi: lo_hi[1] - lo_hi[0])(shard.shard_range(len(s), rank, world)) for v, s in VOICES.items()}
+assert uploads and all(u <= 2 * max(n_mine.values()) for u in uploads), uploads          # this rank's blocks (nat + syn), never a whole voice
+dist.barrier()
+res = base / "Out" / "results"
+for v in ("v1", "v3"):
+    for f in ("BDD_ssml.csv", "BDD_syntagme_ssml.csv", "BDD_syntagme_for_synth.csv", "OUT.TextGrid", "OUT.txt", "used_config.yaml"):
+        assert (res / v / f).exists(), (v, f)
+    assert sorted(p.name for p in (base / "Data" / "voice" / v / "WhisperTS_textgrid_files").glob("*.TextGrid")) == \
+        sorted(f"segment_ph{k + 1}.TextGrid" for k in range(len(VOICES[v])))
+assert not (res / "bad" / "BDD_ssml.csv").exists()
+dims = dict(BW.DIMS["tiny"], n_pos=128)
+piece = lambda wd: [3 + (sum(map(ord, wd)) % 250), 5 + len(wd) % 200][: 1 + len(wd) % 2]
+ap = AP.AudioPipeline("v1", cfg_for(["v1"], model_root), base=base)
+labels = ap.predict_breaks(word_piecer=piece, weights=BW.synthetic_weights(dims, seed=5), dims=dims, cls_id=1, sep_id=2)
+assert len(gathers) == 4 and list(labels) == [f"segment_ph{k + 1}" for k in range(5)]
+dist.barrier()
+sharded = {v: snapshot(base, v) for v in ("v1", "v3")}
+sharded_labels = {k: list(v) for k, v in labels.items()}
+dist.barrier(); dist.destroy_process_group()
+dist.all_gather_into_tensor = _orig
+
+# ---- the same voices by ONE process (no process group) on the same engine: every file identical, text for text
+if rank == 0:
+    AP.AudioPipeline.run = _run
+    solo = base / "solo"
+    lay_out(solo)
+    assert AP.run_all(cfg_for(["v1", "v3"], model_root), base=solo) == []
+    ap1 = AP.AudioPipeline("v1", cfg_for(["v1"], model_root), base=solo)
+    l1 = ap1.predict_breaks(word_piecer=piece, weights=BW.synthetic_weights(dims, seed=5), dims=dims, cls_id=1, sep_id=2)
+    assert {k: list(v) for k, v in l1.items()} == sharded_labels
+    n_rows = 0
+    for v in ("v1", "v3"):
+        one = snapshot(solo, v)
+        assert sorted(one) == sorted(sharded[v]), sorted(set(one) ^ set(sharded[v]))
+        for rel in one:
+            if one[rel] != sharded[v][rel]:
+                import difflib
+                print("\n".join(list(difflib.unified_diff(one[rel].splitlines(), sharded[v][rel].splitlines(), "world1", "world2", lineterm="", n=1))[:60]))
+            assert one[rel] == sharded[v][rel], rel
+        n_rows += len(one[f"Out/results/{v}/BDD_syntagme_ssml.csv"].splitlines()) - 1
+    assert n_rows >= 8, n_rows
+eng.close()
+print("rank", rank, "ok")
+'''
+
+
+def test_run_all_with_the_real_engine_at_world2_and_a_rank_local_failure(tmp_path):
+    script = tmp_path / "w2.py"
+    script.write_text(_WORKER)
+    port = str(29400 + os.getpid() % 140)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=_env()) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900)[0].decode())
+        except subprocess.TimeoutExpired:
+            p.kill(); outs.append("timeout: " + p.communicate()[0].decode())
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-6000:]
