@@ -37,7 +37,12 @@ extern "C" {
  * symbols (tests/test_abi_and_shard.py compares `nm -D` with this header, both ways). */
 #pragma GCC visibility push(default)
 
+/* PCE_API_VERSION changes when an existing entry point changes its signature or is removed; PCE_API_MINOR counts additive changes and
+ * changes of observable defaults:  1 = round 4's default operand mode (fp16 operands + fp16 residual stream), decode loop without the
+ * n_text_ctx pre-check;  2 = round 5: pce_levenshtein, pce_whisper_align_paths_enqueue / _wait, no frame limit in pce_pitch_run, the 256 x 256
+ * GEMM for every batch size (a clip's Whisper results no longer depend on what it is batched with), unknown PCE_WHISPER_OPERANDS rejected. */
 #define PCE_API_VERSION 1
+#define PCE_API_MINOR 2
 
 typedef struct pce_ctx pce_ctx;
 
@@ -75,6 +80,7 @@ void pce_destroy(pce_ctx *ctx);
 const char *pce_last_error(const pce_ctx *ctx);
 int pce_sync(pce_ctx *ctx);
 int pce_api_version(void);
+int pce_api_minor(void);
 int pce_device_info(pce_ctx *ctx, char *name, size_t namelen, int32_t *compute_units, int64_t *hbm_bytes);
 
 /* ---- batch residency ---------------------------------------------------
@@ -219,8 +225,10 @@ int pce_pyin_fetch(pce_ctx *ctx, int32_t clip, int32_t *states, double *voiced_p
  * (Code/Aligners/use_whisper_timestamped.py:139,150-163; openai-whisper==20240930):
  * whisper.log_mel_spectrogram on the 30 s window starting at sample 0 of every
  * uploaded clip (16 kHz; shorter clips are zero padded, as whisper.pad_or_trim
- * does), then AudioEncoder.forward.  Matmuls run in bf16 on MFMA with fp32
- * accumulation; the residual stream is fp32.
+ * does), then AudioEncoder.forward.  Matmuls run on MFMA in the context's
+ * operand mode (pce_whisper_set_operands; default: fp16 operands and an fp16
+ * residual stream, openai-whisper's own fp16 arithmetic) with fp32 accumulation
+ * and fp32 LayerNorm / softmax statistics.
  *
  * Weight blob (float32, this order; Linear/Conv weights in PyTorch layout):
  *   conv1.weight[d][n_mels][3] conv1.bias[d] conv2.weight[d][d][3] conv2.bias[d]
@@ -388,8 +396,9 @@ int pce_levenshtein(pce_ctx *ctx, const uint32_t *a_chars, const int64_t *a_off,
  * (bert-base-multilingual-uncased, num_labels = 2, MAX_LENGTH = 128; the reference has training code only: this is the
  * inference path a pipeline step would call).  weights: the float32 state_dict flattened in the order of
  * prosody-control-french-tts_amd/bert_weights.py:tensor_order.  Sequences are token ids (tokenisation is host logic and
- * needs the checkpoint's vocabulary); token_type_ids = 0, right padding is implicit in the offsets.  bf16 MFMA
- * operands, fp32 accumulation, LayerNorm / residual stream / logits in fp32. */
+ * needs the checkpoint's vocabulary); token_type_ids = 0, right padding is implicit in the offsets.  MFMA operands of
+ * the context's operand mode (pce_whisper_set_operands: fp16 by default, bf16 on request), fp32 accumulation, LayerNorm /
+ * residual stream / logits in fp32. */
 typedef struct pce_bert_dims { int32_t n_vocab, n_pos, n_type, n_state, n_head, n_layer, n_labels; } pce_bert_dims;
 int pce_bert_load(pce_ctx *ctx, const pce_bert_dims *dims, const float *weights, int64_t n_floats);
 int pce_bert_run(pce_ctx *ctx, const int32_t *input_ids, const int32_t *offsets /* [n_seq + 1] */, int32_t n_seq);

@@ -85,6 +85,7 @@ void pce_profile_collect(pce_ctx *ctx, bool wait)
 extern "C" {
 
 int pce_api_version(void) { return PCE_API_VERSION; }
+int pce_api_minor(void) { return PCE_API_MINOR; }
 
 pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
 {
@@ -125,6 +126,13 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
         // default (round 4): fp16 operands AND the fp16 residual stream, the reference's own arithmetic end to end (openai-whisper fp16=True);
         // measured against the fp32 restatement at Whisper-small depth (tools/operand_precision.py, profiles/r04): encoder rel-L2 1.0e-3,
         // every word boundary identical, no greedy flip in 2 112 steps; "fp16" keeps the fp32 stream (4.6e-4), "bf16" the round-1 / 2 arithmetic
+        if (ops && *ops && strcmp(ops, "bf16") && strcmp(ops, "fp16") && strcmp(ops, "fp16-resid16")) {
+            // a misspelt mode must not silently select the default
+            if (err && errlen) snprintf(err, errlen, "PCE_WHISPER_OPERANDS=%s: bf16, fp16 or fp16-resid16", ops);
+            if (c->own_stream) (void)hipStreamDestroy(c->stream);
+            delete c;
+            return nullptr;
+        }
         c->whisper_ops = (ops && !strcmp(ops, "bf16")) ? 0 : (ops && !strcmp(ops, "fp16")) ? 1 : 2;
         c->resid16 = c->whisper_ops == 2;
     }

@@ -104,7 +104,7 @@ KERNEL_IDS = ["k_energy", "k_lufs_pass1", "k_lufs_scan", "k_lufs_pass2", "k_lufs
               "whisper_decode_loop", "k_cross_attn1", "k_gemm_skinny", "k_levenshtein"]     # = pce_kernel_name(id) for every id (tests/test_abi_and_shard.py)
 
 # every symbol include/pce.h declares
-EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_device_info",
+EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_version", "pce_api_minor", "pce_device_info",
            "pce_upload_pcm_s16", "pce_bind_pcm_s16_device", "pce_num_clips",
            "pce_energy_run", "pce_energy_fetch", "pce_lufs_set_meter_rate", "pce_lufs_run", "pce_lufs_fetch",
            "pce_frame_energy_run", "pce_frame_energy_shape", "pce_frame_energy_fetch", "pce_pyin_run", "pce_pyin_shape", "pce_pyin_fetch",
@@ -129,6 +129,7 @@ def load_library() -> C.CDLL:
     lib.pce_last_error.argtypes = [vp]; lib.pce_last_error.restype = C.c_char_p
     lib.pce_sync.argtypes = [vp]
     lib.pce_api_version.argtypes = []
+    lib.pce_api_minor.argtypes = []
     lib.pce_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(i64)]
     lib.pce_upload_pcm_s16.argtypes = [vp, vp, vp, i32, i32]
     lib.pce_bind_pcm_s16_device.argtypes = [vp, vp, vp, i32, i32]
@@ -424,7 +425,10 @@ class ProsodyEngine:
 
     @property
     def whisper_operands(self) -> str:
-        return {0: "bf16", 1: "fp16", 2: "fp16-resid16"}[self._lib.pce_whisper_get_operands(self._ctx)]
+        code = self._lib.pce_whisper_get_operands(self._ctx)
+        if code < 0:
+            self._check(code)
+        return {0: "bf16", 1: "fp16", 2: "fp16-resid16"}.get(code, f"mode-{code}")
 
     def _op_dtype(self):
         import torch

@@ -30,7 +30,7 @@ def test_build_and_exports_match_header():
     exported = {ln.split()[-1] for ln in nm if ln.strip()}
     assert exported == declared, sorted(exported ^ declared)
     lib.pce_api_version.restype = ctypes.c_int
-    assert lib.pce_api_version() == 1
+    assert lib.pce_api_version() == 1 and lib.pce_api_minor() >= 2
     lib.pce_kernel_name.restype = ctypes.c_char_p
     assert [lib.pce_kernel_name(i).decode() for i in range(len(E.KERNEL_IDS))] == E.KERNEL_IDS
     # struct layouts the ctypes side assumes
