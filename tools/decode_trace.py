@@ -30,6 +30,24 @@ def summarise(d):
               f"memory copies between the first and the last step: {len(inside)} ({sum(nbytes)} bytes: {sorted(set(nbytes))})")
 
 
+    # where a step's time goes (last loop): per kernel launches / mean duration / time per step, and the gaps between consecutive kernels
+    import re, collections
+    lp = loops[-1]
+    a, b = int(lp[0]["Start_Timestamp"]), int(lp[-1]["End_Timestamp"])
+    kin = sorted((r for r in K if a <= int(r["Start_Timestamp"]) <= b), key=lambda r: int(r["Start_Timestamp"]))
+    steps = max(len(lp) - 1, 1)
+    acc = collections.defaultdict(lambda: [0, 0])
+    for r in kin:
+        m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", r["Kernel_Name"])
+        name = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
+        acc[name][0] += 1; acc[name][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    gaps = [int(y["Start_Timestamp"]) - int(x["End_Timestamp"]) for x, y in zip(kin, kin[1:])]
+    print(f"last loop, per step: {len(kin) / steps:.1f} kernels; gaps between consecutive kernels: mean {sum(gaps) / len(gaps) / 1e3:.2f} us, "
+          f"sum per step {sum(g for g in gaps if g > 0) / steps / 1e3:.1f} us, overlapped (negative) {sum(1 for g in gaps if g < 0)}")
+    for name, (cnt, ns) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {name:60s} {cnt / steps:6.1f} per step  {ns / cnt / 1e3:8.2f} us each  {ns / steps / 1e3:8.1f} us per step")
+
+
 if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
     summarise(sys.argv[2]); sys.exit(0)
 
