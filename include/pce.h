@@ -372,7 +372,7 @@ int pce_dtw(pce_ctx *ctx, const double *x, int32_t n_rows, int32_t n_cols, int32
 
 /* ---- batched Needleman-Wunsch word alignment ------------------------------
  * Replaces needleman_wunsch (Code/Pipeline/NeedlemanWunschAlignement.py:27-81) for a batch of sequence pairs.
- * Pair b aligns a_ids[a_off[b] .. a_off[b+1]) (rows, at most 1024) with b_ids[b_off[b] .. b_off[b+1]); the ids are
+ * Pair b aligns a_ids[a_off[b] .. a_off[b+1]) (rows; any number since round 5) with b_ids[b_off[b] .. b_off[b+1]); the ids are
  * the host's integer codes of the normalised tokens (:43-47), equal ids = equal tokens.  Scores as the reference's
  * keyword arguments (match 1, mismatch -1, gap -1).  Output for pair b starts at element
  * sum_{p<b} (len_a[p] + len_b[p]) of out_i / out_j and has out_len[b] steps in alignment order: (i, j) = a

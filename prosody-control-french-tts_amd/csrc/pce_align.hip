@@ -82,42 +82,51 @@ __global__ __launch_bounds__(DTW_MAXN) void k_dtw(const double *__restrict__ x, 
 // score[i][0] = i gap, score[0][j] = j gap; the trace-back tests "diagonal, then up, else left" (:69-80) against
 // the finished matrix, which is the same as recording, per cell, the FIRST of (diagonal, up, left) that attains the
 // maximum.  Tokens are compared on the host-normalised integer ids.  Integer arithmetic: the alignment is exactly
-// the reference's.  Same wavefront as k_dtw: one workgroup per pair, thread = row, two previous anti-diagonals in LDS.
+// the reference's.  Same wavefront as k_dtw: one workgroup per pair, thread = row, two previous anti-diagonals in LDS; more
+// than 1 024 rows are swept in stripes of 1 024 (no length limit).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(DTW_MAXN) void k_nw(const int *__restrict__ a_ids, const long long *__restrict__ a_off, const int *__restrict__ b_ids,
                                                 const long long *__restrict__ b_off, int match, int mismatch, int gap,
                                                 unsigned char *__restrict__ trace, const long long *__restrict__ tr_off,
                                                 int *__restrict__ out_i, int *__restrict__ out_j, const long long *__restrict__ out_off,
-                                                int *__restrict__ out_len)
+                                                int *__restrict__ out_len, int *__restrict__ rows, const long long *__restrict__ rows_off)
 {
     __shared__ int diag[3][DTW_MAXN + 1];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.x, t = threadIdx.x, S = (int)blockDim.x;
     const int N = (int)(a_off[b + 1] - a_off[b]), M = (int)(b_off[b + 1] - b_off[b]);
     const int *A = a_ids + a_off[b], *B = b_ids + b_off[b];
     unsigned char *tr = trace + tr_off[b];                // [(N+1) x (M+1)]
-    // diagonal D holds score[r][D - r]; thread t owns row r = t + 1, row 0 is the boundary
-    const int r = t + 1;
-    const int my_a = t < N ? A[t] : 0;
-    if (t == 0) { diag[0][0] = 0; diag[1][0] = gap; }    // score[0][0], score[0][1]
-    if (t < N && r == 1) diag[1][1] = gap;               // score[1][0]
-    __syncthreads();
-    for (int D = 2; D <= N + M; D++) {
-        int *cur = diag[D % 3]; const int *p1 = diag[(D - 1) % 3], *p2 = diag[(D - 2) % 3];
-        const int c = D - r;
-        if (t < N) {
-            if (c >= 1 && c <= M) {
-                const int dg = p2[r - 1] + (my_a == B[c - 1] ? match : mismatch), up = p1[r - 1] + gap, lf = p1[r] + gap;
-                int best = dg; unsigned char tt = 0;
-                if (up > best) { best = up; tt = 1; }
-                if (lf > best) { best = lf; tt = 2; }
-                cur[r] = best;
-                tr[(size_t)r * (M + 1) + c] = tt;
-            } else if (c == 0) {
-                cur[r] = r * gap;                         // score[r][0]
-            }
-        }
-        if (t == 0 && D <= M) cur[0] = D * gap;           // score[0][D]
+    // Rows are swept in stripes of blockDim.x (round 5: any number of rows; one stripe is the old kernel).  Inside a stripe, local diagonal
+    // D holds score[r0 + lr][D - lr] at index lr; thread t owns local row lr = t + 1, index 0 is the row above the stripe: the boundary
+    // row score[0][c] = c gap for the first stripe, the previous stripe's last row (handed over through `top`, global) for the others.
+    int *top = rows + rows_off[b], *bot = top + (M + 1);  // only touched when N > blockDim.x
+    for (int r0 = 0; r0 < N; r0 += S) {
+        const int R = min(S, N - r0), lr = t + 1, gr = r0 + lr;
+        const bool first = r0 == 0, more = r0 + S < N;
+        const int my_a = t < R ? A[gr - 1] : 0;
+        if (t == 0) diag[0][0] = r0 * gap;                // score[r0][0]
+        int tv = (t == 0 && M >= 1) ? (first ? gap : top[1]) : 0;         // score[r0][D] for the coming diagonal, fetched one step ahead
         __syncthreads();
+        for (int D = 1; D <= R + M; D++) {
+            int *cur = diag[D % 3]; const int *p1 = diag[(D + 2) % 3], *p2 = diag[(D + 1) % 3];
+            const int c = D - lr;
+            if (t < R) {
+                if (c >= 1 && c <= M) {
+                    const int dg = p2[lr - 1] + (my_a == B[c - 1] ? match : mismatch), up = p1[lr - 1] + gap, lf = p1[lr] + gap;
+                    int best = dg; unsigned char tt = 0;
+                    if (up > best) { best = up; tt = 1; }
+                    if (lf > best) { best = lf; tt = 2; }
+                    cur[lr] = best;
+                    tr[(size_t)gr * (M + 1) + c] = tt;
+                    if (more && lr == R) bot[c] = best;   // the stripe's last row: the next stripe's boundary
+                } else if (c == 0) {
+                    cur[lr] = gr * gap;                   // score[gr][0]
+                }
+            }
+            if (t == 0 && D <= M) { cur[0] = tv; if (D + 1 <= M) tv = first ? (D + 1) * gap : top[D + 1]; }      // score[r0][D]
+            __syncthreads();
+        }
+        if (more) { __threadfence(); __syncthreads(); int *x = top; top = bot; bot = x; }
     }
     __threadfence_block();
     if (t == 0) {
@@ -254,20 +263,22 @@ int pce_nw_align(pce_ctx *c, const int32_t *a_ids, const int64_t *a_off, const i
 {
     if (!c || !a_off || !b_off || !out_i || !out_j || !out_len || batch <= 0) return PCE_E_INVALID;
     PCE_HIP(c, hipSetDevice(c->device));
-    std::vector<long long> tro((size_t)batch + 1, 0), oo((size_t)batch + 1, 0);
+    std::vector<long long> tro((size_t)batch + 1, 0), oo((size_t)batch + 1, 0), rwo((size_t)batch + 1, 0);
     int max_rows = 0;
     for (int32_t b = 0; b < batch; b++) {
         const int64_t n = a_off[b + 1] - a_off[b], m = b_off[b + 1] - b_off[b];
         if (n < 0 || m < 0) return pce_fail(c, PCE_E_INVALID, "pce_nw_align: offsets of pair %d decrease", b);
-        if (n > DTW_MAXN) return pce_fail(c, PCE_E_LIMIT, "pce_nw_align: pair %d has %lld rows (limit %d)", b, (long long)n, DTW_MAXN);
+        if (n > 0x3fffffff || m > 0x3fffffff) return pce_fail(c, PCE_E_LIMIT, "pce_nw_align: pair %d is longer than 2^30 tokens", b);
         tro[(size_t)b + 1] = tro[(size_t)b] + (n + 1) * (m + 1);
+        rwo[(size_t)b + 1] = rwo[(size_t)b] + (n > DTW_MAXN ? 2 * (m + 1) : 0);       // stripe hand-over rows (ping-pong)
         oo[(size_t)b + 1] = oo[(size_t)b] + n + m;
         if (n > max_rows) max_rows = (int)n;
     }
     const size_t na = (size_t)a_off[batch], nb = (size_t)b_off[batch], no = (size_t)oo[(size_t)batch];
     if (a_off[0] != 0 || b_off[0] != 0) return pce_fail(c, PCE_E_INVALID, "pce_nw_align: offsets must start at 0");
     if ((na && !a_ids) || (nb && !b_ids)) return PCE_E_INVALID;
-    DevBuf da, db, dao, dbo, dtr, dtro, doi, doj, doo, dol;
+    DevBuf da, db, dao, dbo, dtr, dtro, doi, doj, doo, dol, drw, drwo;
+    PCE_HIP(c, drw.reserve(sizeof(int) * ((size_t)rwo[(size_t)batch] + 1))); PCE_HIP(c, drwo.reserve(sizeof(long long) * ((size_t)batch + 1)));
     PCE_HIP(c, da.reserve(sizeof(int) * (na + 1))); PCE_HIP(c, db.reserve(sizeof(int) * (nb + 1)));
     PCE_HIP(c, dao.reserve(sizeof(long long) * ((size_t)batch + 1))); PCE_HIP(c, dbo.reserve(sizeof(long long) * ((size_t)batch + 1)));
     PCE_HIP(c, dtr.reserve((size_t)tro[(size_t)batch] + 1)); PCE_HIP(c, dtro.reserve(sizeof(long long) * ((size_t)batch + 1)));
@@ -279,12 +290,13 @@ int pce_nw_align(pce_ctx *c, const int32_t *a_ids, const int64_t *a_off, const i
     PCE_HIP(c, hipMemcpyAsync(dbo.p, b_off, sizeof(long long) * ((size_t)batch + 1), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipMemcpyAsync(dtro.p, tro.data(), sizeof(long long) * tro.size(), hipMemcpyHostToDevice, c->stream));
     PCE_HIP(c, hipMemcpyAsync(doo.p, oo.data(), sizeof(long long) * oo.size(), hipMemcpyHostToDevice, c->stream));
-    int threads = 64; while (threads < max_rows) threads <<= 1;
+    PCE_HIP(c, hipMemcpyAsync(drwo.p, rwo.data(), sizeof(long long) * rwo.size(), hipMemcpyHostToDevice, c->stream));
+    int threads = 64; while (threads < max_rows && threads < DTW_MAXN) threads <<= 1;
     {
         KernelTimer t(c, PCE_K_NW);
         hipLaunchKernelGGL(k_nw, dim3((unsigned)batch), dim3((unsigned)threads), 0, c->stream, da.as<int>(), dao.as<long long>(), db.as<int>(),
                            dbo.as<long long>(), match, mismatch, gap, dtr.as<unsigned char>(), dtro.as<long long>(), doi.as<int>(), doj.as<int>(),
-                           doo.as<long long>(), dol.as<int>());
+                           doo.as<long long>(), dol.as<int>(), drw.as<int>(), drwo.as<long long>());
     }
     PCE_HIP(c, hipGetLastError());
     if (no) {
@@ -294,7 +306,7 @@ int pce_nw_align(pce_ctx *c, const int32_t *a_ids, const int64_t *a_off, const i
     PCE_HIP(c, hipMemcpyAsync(out_len, dol.p, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
-    for (DevBuf *x : {&da, &db, &dao, &dbo, &dtr, &dtro, &doi, &doj, &doo, &dol}) x->release();
+    for (DevBuf *x : {&da, &db, &dao, &dbo, &dtr, &dtro, &doi, &doj, &doo, &dol, &drw, &drwo}) x->release();
     return PCE_OK;
 }
 

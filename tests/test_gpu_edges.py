@@ -163,7 +163,7 @@ def test_nw_align_gpu_reproduces_the_reference_alignments(engine, tmp_path):
     rng = np.random.default_rng(5)
     words = ["le", "la", "chat", "Chat.", "mange", "souris,", "une", "et", "ß", "oui?"]
     extra = []
-    for n, m in [(0, 0), (0, 5), (7, 0), (1, 1), (40, 37), (300, 280), (64, 65)]:
+    for n, m in [(0, 0), (0, 5), (7, 0), (1, 1), (40, 37), (300, 280), (64, 65), (1024, 1000), (1025, 30), (2300, 2250)]:   # (beyond 1 024 rows: striped)
         mk = lambda k: [(str(i), words[int(rng.integers(len(words)))], float(i), float(i) + 0.5, 0.5) for i in range(k)]
         extra.append((mk(n), mk(m)))
     for (a, b), g in zip(extra, NW.needleman_wunsch_batch(extra, engine)):
