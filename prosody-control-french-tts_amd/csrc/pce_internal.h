@@ -93,6 +93,7 @@ struct pce_ctx {
     double pi_P[32] = {0};          // PiParams image
     int64_t pi_n_work = 0, pi_n_energy_work = 0;
     int pi_np2 = 1;
+    bool attn_m16 = false;          // attention on v_mfma_f32_16x16x32 (k_attention_lean16) instead of 32x32x16
     bool pi_long_slices = false;    // some slice has more frames than the in-LDS median sort holds (k_pitch_median_long takes those)
     SliceCache pi_cache;
     pce_pitch_params pi_params;
