@@ -34,14 +34,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (never the 2:1-sparsity figure)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s fp32 vector rate (AMD's MI355X fp64 vector figure; the guide has no fp64 row)
 VALU_F64_PEAK_TFLOPS = 78.6     # fp64 vector peak (79 TF/s)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 COMPOSITE = ("whisper_encoder", "whisper_align", "bert_forward", "whisper_decode_step", "whisper_decode_loop")   # brackets around several launches
 
 
 def load_pmc_traffic(workload):
     """HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 for the gfx950 wide-read
     under-count + WRITE_SIZE, KB -> B; tools/pmc_traffic.py), committed under profiles/."""
-    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r03")):        # (the previous round's passes until this round's are committed)
+    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r04")):        # (the previous round's passes until this round's are committed)
         try:
             with open(os.path.join(d, f"pmc_traffic_{workload}.json")) as f:
                 out = json.load(f)["bytes_per_launch"]
@@ -205,6 +205,8 @@ def main():
                     "measurement (log-mel + encoder + device-resident decoding loop + forced alignment; never `value`); 0 = skip")
     ap.add_argument("--medium-steps", type=int, default=2, help="c3 with --whisper-model small on one GPU: extra steps with Whisper-medium dims (the "
                     "reference's default model) for the `medium` object; 0 = skip")
+    ap.add_argument("--prosody-context", type=int, default=0, help="c3: 1 = the prosody leg (energy, LUFS, F0, STFT-dB) runs in a SECOND engine context (its own "
+                    "HIP streams) on the same resident PCM, beside the Whisper leg instead of behind it")
     ap.add_argument("--framing-clips", type=int, default=1250, help="clips of the extra `framing_hbm` measurement (k_energy / k_frame_energy beyond the Infinity "
                     "Cache: the per-GPU shard of BASELINE config 4); 0 = skip")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered per-utterance records of the last timed step to this .npy file")
@@ -291,10 +293,24 @@ def run_rank(args, world, rank, local_rank):
     _, _, local_rank = shard.init_from_env()
     torch.cuda.set_device(local_rank)
     eng = pkg.ProsodyEngine(local_rank)
-    eng.upload(clips, rate)                      # inputs resident in HBM before the timed region
-    sl = eng.whole_clip_slices()
+    pe = eng                                     # the context the prosody leg runs in
+    if wdims and args.prosody_context:
+        # two contexts on one device = two sets of HIP streams over ONE resident copy of the batch: the VALU-bound prosody kernels fill the
+        # tails and the HBM-bound passes of the MFMA leg instead of queueing behind it
+        pe = pkg.ProsodyEngine(local_rank)
+        flat_pcm = torch.from_numpy(np.concatenate(clips)).to("cuda")
+        pad = torch.zeros(64, dtype=torch.int16, device="cuda")
+        pcm_dev = torch.cat([flat_pcm, pad])
+        offs_dev = np.zeros(len(clips) + 1, dtype=np.int64); np.cumsum([len(c) for c in clips], out=offs_dev[1:])
+        torch.cuda.synchronize()
+        eng.bind_device(pcm_dev.data_ptr(), offs_dev, rate, keepalive=pcm_dev)
+        pe.bind_device(pcm_dev.data_ptr(), offs_dev, rate, keepalive=pcm_dev)
+        args.streamed_steps = 0
+    else:
+        eng.upload(clips, rate)                  # inputs resident in HBM before the timed region
+    sl = pe.whole_clip_slices()
     params = pkg.PitchParams.praat(float(os.environ.get("PCE_BENCH_FLOOR", "150")), 600.0)   # reference: floor 150 (Code/audioPipeline.py:329)
-    off, _ = eng.pitch_plan(sl, params)
+    off, _ = pe.pitch_plan(sl, params)
     n_pitch_frames = int(off[1] - off[0])
     n_stft_frames = 1 + n_samples // 256
     if wdims:
@@ -311,11 +327,11 @@ def run_rank(args, world, rank, local_rank):
             eng.whisper_encode_run()
             eng.whisper_align_run(align_tokens, align_frames, sot_len)   # teacher-forced decoder + cross-attention weights + DTW
             eng.whisper_align_paths_enqueue(slot)                        # every clip's (token, frame) path -> pinned host memory, asynchronously
-        eng.energy_run(sl, 500)
-        eng.lufs_run(sl)
-        eng.pitch_run(sl, params)
-        eng.stft_db_run(1024, 256)
-        eng.stats_enqueue(slot)
+        pe.energy_run(sl, 500)
+        pe.lufs_run(sl)
+        pe.pitch_run(sl, params)
+        pe.stft_db_run(1024, 256)
+        pe.stats_enqueue(slot)
 
     path_steps = []                                                # DTW path steps that reached the host per step (c3)
 
@@ -323,7 +339,7 @@ def run_rank(args, world, rank, local_rank):
         if wdims:
             pl, _, _ = eng.whisper_align_paths_wait(slot)           # what a pipeline writes TextGrids from: the alignment leaves the device inside the step
             path_steps.append(int(pl.sum()))
-        r = eng.stats_wait(slot)
+        r = pe.stats_wait(slot)
         en, lu, pi = r["energy"], r["lufs"][0], r["pitch"]
         # per-utterance record: [median F0, LUFS, rms, peak, silence ratio, duration, n_voiced]
         rec = np.stack([pi["median_f0"], lu, np.sqrt(en["sum_sq"] / np.maximum(en["n"], 1)), en["peak_abs"].astype(np.float64),
@@ -349,11 +365,15 @@ def run_rank(args, world, rank, local_rank):
             dist.barrier()
         torch.cuda.synchronize()
         eng.sync()
+        if pe is not eng:
+            pe.sync()
 
     run_steps(args.warmup)
     if not args.no_profile:
         eng.profile_enable(True)
         eng.profile_reset()
+        if pe is not eng:
+            pe.profile_enable(True); pe.profile_reset()
     fence()
     done_at.clear()
     t0 = time.perf_counter()
@@ -368,6 +388,10 @@ def run_rank(args, world, rank, local_rank):
               if len(iv) > 1 else None)
     prof = eng.profile() if not args.no_profile else {}
     eng.profile_enable(False)
+    if pe is not eng:
+        if not args.no_profile:
+            prof.update(pe.profile())
+        pe.profile_enable(False)
 
     t_max = torch.tensor([dt], dtype=torch.float64, device="cuda" if world == 1 or dist.get_backend() == "nccl" else "cpu")
     if world > 1:
@@ -489,7 +513,7 @@ def run_rank(args, world, rank, local_rank):
 
             def m_step():
                 eng.logmel_run(md["n_mels"]); eng.whisper_encode_run(); eng.whisper_align_run(m_tokens, align_frames, sot_len)
-                eng.energy_run(sl, 500); eng.lufs_run(sl); eng.pitch_run(sl, params); eng.stft_db_run(1024, 256)
+                pe.energy_run(sl, 500); pe.lufs_run(sl); pe.pitch_run(sl, params); pe.stft_db_run(1024, 256)
             m_step(); fence()
             eng.profile_enable(True); eng.profile_reset()
             tm0 = time.perf_counter()
@@ -672,10 +696,13 @@ def run_rank(args, world, rank, local_rank):
             "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {args.clips} synthetic {args.seconds:g} s 16 kHz mono clips per GPU, " + what,
                        "clips_per_gpu": args.clips, "clip_seconds": args.seconds, "sample_rate": rate,
-                       "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)"},
+                       "parallelism": f"utterance-sharded x{world}, one all-gather of 7 fp64 stats per clip (no other collective)",
+                       "prosody_context": bool(pe is not eng)},
             "roofline": roofline, "framing_hbm": framing, "alignment_path_steps_per_step": (path_steps[-1] if path_steps else None), "mfma_floor": floor, "gemm_shapes": gemm_shapes, "stages": rows, "kernels": kernels, "pmc_traffic_bytes_per_launch": traffic, "cpu_baseline": cpu,
             "streamed_value": streamed, "transcribe": transcribe, "medium": medium, "device": info["name"], "host_cores": os.cpu_count(),
         }))
+    if pe is not eng:
+        pe.close()
     eng.close()
     if world > 1:
         dist.destroy_process_group()
