@@ -347,3 +347,38 @@ def test_failure_flags_without_a_process_group():
     segs = [T.SegmentInput("segment_ph1", [(0.0, 0.4, "bonjour"), (0.4, 0.6, " "), (0.6, 1.0, "monde.")])]
     with pytest.raises(OSError, match="device lost"):
         tg.run_sharded(segs, Broken(), 0, 1, shard.allgather_records)
+
+
+def test_init_from_env_without_a_launcher_and_its_overrides(monkeypatch):
+    """shard.init_from_env: no process group without WORLD_SIZE > 1; the device follows LOCAL_RANK unless PCE_RANK_DEVICE names it; an
+    unknown PCE_DIST_BACKEND is refused before anything is initialised (the world-2 runs themselves: tests/test_gpu_world2.py on the GPU,
+    the gloo workers above on CPU)."""
+    import torch.distributed as dist
+    from prosody_control_french_tts_amd import shard
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PCE_RANK_DEVICE", "PCE_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    assert shard.init_from_env() == (0, 1, 0) and not dist.is_initialized()
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert shard.local_device() == 3 and shard.init_from_env() == (0, 1, 3)
+    monkeypatch.setenv("PCE_RANK_DEVICE", "0")
+    assert shard.local_device() == 0
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("PCE_DIST_BACKEND", "mpi")
+    with pytest.raises(ValueError):
+        shard.init_from_env()
+    assert not dist.is_initialized()
+
+
+def test_default_engine_is_keyed_by_device():
+    """engine.get_default_engine: one context per process; asking for another device than the existing engine's is an error, not a silent
+    run on the wrong GPU (a stand-in engine: no GPU here)."""
+    from prosody_control_french_tts_amd import engine as E
+
+    class Stub:
+        device = 2
+    E.set_default_engine(Stub())
+    try:
+        assert E.get_default_engine() is E.get_default_engine(2)
+        with pytest.raises(RuntimeError):
+            E.get_default_engine(0)
+    finally:
+        E.set_default_engine(None)
