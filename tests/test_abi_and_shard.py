@@ -315,6 +315,12 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert out.returncode == 0, out.stderr.decode()
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["exchange_ok"] and line["records"] == 14
+    # the node size the driver launches (N = 8): eight rank processes, one padded all-gather, records in rank order
+    out8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--clips", "5", "--selftest-launcher"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out8.returncode == 0, out8.stderr.decode()[-2000:]
+    line8 = json.loads(out8.stdout.decode().strip().splitlines()[-1])
+    assert line8["n_gpus"] == 8 and line8["exchange_ok"] and line8["records"] == 40
     # a rank whose WORLD_SIZE contradicts --gpus refuses to run instead of silently reporting n_gpus = 1
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-launcher"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
