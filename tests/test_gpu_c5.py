@@ -8,9 +8,12 @@ code: a random-init miniature Whisper / BERT written as checkpoint files (no tra
 chain they drive is the real one) and a deterministic raw-synthesis stand-in derived from the natural audio (the "Raw Synthesis" step is
 an Azure call: out of scope, skipped with a warning as in every run of this package).
 
-The diff: the three CSVs of the step are rebuilt by ``SsmlTagger`` fed by the CPU ORACLE's measurements over the TextGrids the aligner
-has just written (the reference's closures on the restated Praat / pyloudnorm / pydub arithmetic with the reference's meters), and must
-be text-identical; F0 medians within 1e-6 relative, LUFS within 1e-6 LU, durations equal.  The 8-rank half of configs[4] needs a node
+The diff is a MEASUREMENT diff, not an independent SSML diff: the three CSVs of the step are rebuilt by the SAME ``SsmlTagger`` (product code on
+both sides) fed by the CPU ORACLE's measurements over the TextGrids the aligner has just written (the reference's closures on the restated
+Praat / pyloudnorm / pydub arithmetic with the reference's meters), and must be text-identical; F0 medians within 1e-6 relative, LUFS within
+1e-6 LU, durations equal.  What it shows is that the GPU's measurements lead to the same tables as the CPU's; that the tagger turns measurements
+into the reference's strings is pinned separately, on CPU, by golden G7 (the reference's own ``measure_prosody_and_build_ssml`` run with
+scripted measurements: tests/test_goldens.py).  The Whisper / BERT checkpoints are random-init miniatures: the chain is real, the words are noise.  The 8-rank half of configs[4] needs a node
 this pool does not have: the same chain runs at world size 2 under gloo in tests/test_c5_chain.py.
 """
 import logging
