@@ -420,3 +420,33 @@ def test_whole_recording_of_two_minutes_has_no_frame_limit(engine):
         if k != 1:
             parities.add(int(v.sum()) & 1)
     assert parities == {0, 1}, parities
+
+
+@pytest.mark.gpu
+def test_round5_edge_cases_of_the_unlimited_paths(engine):
+    """Corners of the paths that lost their limits in round 5: a long slice with NO voiced frame (k_pitch_median_long with nothing to select), an
+    exact multiple of the Needleman-Wunsch stripe height against a single column, 20 000 word pairs in one Levenshtein launch, lone surrogates."""
+    from prosody_control_french_tts_amd import PitchParams
+    from prosody_control_french_tts_amd.engine import make_slices
+    from prosody_control_french_tts_amd.Pipeline import NeedlemanWunschAlignement as NW
+    from oracle import oracle as O
+    rng = np.random.default_rng(2)
+    quiet = np.zeros(100 * 16000, dtype=np.int16)                       # 100 s of digital silence: 19 997 frames, all unvoiced
+    quiet[::4001] = 3                                                    # (not identically zero: the frames are analysed, none passes the voicing threshold)
+    engine.upload([quiet], 16000)
+    res = engine.pitch(make_slices([0], [0], [len(quiet)], [0.5 / 16000]), PitchParams.praat(150.0, 600.0))
+    assert res["frame_offsets"][1] == 19997 and res["summary"][0]["n_voiced"] == 0
+    assert res["summary"][0]["median_f0"] == 0.0 and res["summary"][0]["mean_log_f0"] == 0.0 and not (res["f0"] > 0).any()
+    words = ["a", "b", "c", "d."]
+    mk = lambda k: [(str(i), words[int(rng.integers(len(words)))], float(i), float(i) + 0.5, 0.5) for i in range(k)]
+    for n, m in [(2048, 1), (1, 2048), (1024, 1024)]:
+        a, b = mk(n), mk(m)
+        (g,) = NW.needleman_wunsch_batch([(a, b)], engine)
+        assert NW.format_alignment(g) == NW.format_alignment(NW.needleman_wunsch(a, b)), (n, m)
+    vocab = ["le", "la", "les", "monde", "mondes", "bonjour", "bon", "jour", "été", "etait", "cœur", "coeur", ""]
+    pairs = [(vocab[int(i)], vocab[int(j)]) for i, j in rng.integers(0, len(vocab), size=(20000, 2))]
+    got = engine.levenshtein(pairs)
+    table = {(a, b): O.levenshtein(a, b) for a in vocab for b in vocab}
+    assert got.tolist() == [table[p] for p in pairs]
+    lone = [("a\ud800b", "ab"), ("\udfff", ""), ("x\U0001F600y", "x\ud83dy")]     # surrogates are code points like any other to Python's str
+    assert engine.levenshtein(lone).tolist() == [O.levenshtein(a, b) for a, b in lone] == [1, 1, 1]
