@@ -343,7 +343,9 @@ int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_
  * PCE_OPERANDS_F16_RESID16 (round 4): the fp16 build with the encoder's residual stream kept in fp16 as well -- openai-whisper's own
  * `x = x + attn(...)`, `x = x + mlp(...)` are fp16 + fp16 -> fp16, only LayerNorm computes in fp32 (model.py) -- which cuts the bytes of the
  * residual / LayerNorm passes from 22 to 16 per element and layer on the batched encoder path; same state slot as PCE_OPERANDS_FP16 (no
- * reload needed between the two), pce_whisper_get_operands returns the value that was set. */
+ * reload needed between the two), pce_whisper_get_operands returns the value that was set.  The 16-bit stream belongs to the 256 x 256 GEMM path,
+ * which since round 5 runs for EVERY batch size when n_state is a multiple of 256 (base, small, medium, large); a model whose width is not (tiny:
+ * 384; the miniatures of the tests) takes the tiled kernels with the fp32 stream in every mode, for every batch size alike. */
 enum { PCE_OPERANDS_BF16 = 0, PCE_OPERANDS_FP16 = 1, PCE_OPERANDS_F16_RESID16 = 2 };
 int pce_whisper_set_operands(pce_ctx *ctx, int32_t operand_type);
 int pce_whisper_get_operands(pce_ctx *ctx);
