@@ -40,7 +40,8 @@ extern "C" {
 /* PCE_API_VERSION changes when an existing entry point changes its signature or is removed; PCE_API_MINOR counts additive changes and
  * changes of observable defaults:  1 = round 4's default operand mode (fp16 operands + fp16 residual stream), decode loop without the
  * n_text_ctx pre-check;  2 = round 5: pce_levenshtein, pce_whisper_align_paths_enqueue / _wait, no frame limit in pce_pitch_run, the 256 x 256
- * GEMM for every batch size (a clip's Whisper results no longer depend on what it is batched with), unknown PCE_WHISPER_OPERANDS rejected. */
+ * GEMM for every batch size (a clip's Whisper results no longer depend on what it is batched with), unknown PCE_WHISPER_OPERANDS rejected,
+ * pce_whisper_sample_keys (temperature sampling keyed by the caller's clip ids instead of batch positions). */
 #define PCE_API_VERSION 1
 #define PCE_API_MINOR 2
 
@@ -332,6 +333,13 @@ int pce_whisper_decode_step_ex(pce_ctx *ctx, const int32_t *tokens, const int32_
                                const pce_whisper_decode_rules *rules, const uint8_t *vocab_mask, const pce_whisper_decode_opts *opts,
                                int32_t *next_tokens /* [clips] */, float *next_logprobs /* [clips] or NULL */,
                                float *probe_prob /* [clips] or NULL */);
+
+/* What the sampling noise of a clip is keyed by.  The draw at temperature > 0 is a function of (seed, key, position, token); without this
+ * call the key is the clip's position in the encoded batch, so the same recording samples differently when it is batched with other
+ * clips (another shard of a multi-rank run, another batch size).  keys[i]: any int32 that names clip i wherever it is batched (the mirror's
+ * transcribe() passes a hash of the clip's samples and its window start); they hold for the batch now encoded -- the next
+ * pce_whisper_encode_run drops them -- and n must be that batch's clip count (n = 0: drop them now).  PCE_E_STATE before an encoder run. */
+int pce_whisper_sample_keys(pce_ctx *ctx, const int32_t *keys /* [n] */, int32_t n);
 
 /* Operand type of every Whisper / BERT matrix product (round 3).  Default since round 4: PCE_OPERANDS_F16_RESID16 (below; PCE_WHISPER_OPERANDS=fp16
  * or bf16 in the environment at pce_create selects another default).  PCE_OPERANDS_FP16: fp16 operands, the reference's own

@@ -235,6 +235,7 @@ def transcribe_batch(engine, model, tokenizer, clips: Sequence[np.ndarray], opti
     sot_seq = list(tokenizer.sot_sequence(opt.language))
     content = [len(a) // HOP for a in audio]                                # mel frames of content per clip
     seeks = [0] * n
+    clip_ids = [zlib.crc32(np.ascontiguousarray(a, dtype=np.int16).tobytes()) for a in audio]      # (what names a recording: its samples)
     all_tokens: List[List[int]] = [[] for _ in range(n)]                   # text of the previous windows (prompt material)
     prompt_reset = [0] * n
     n_mels = model.dims["n_mels"]
@@ -259,9 +260,12 @@ def transcribe_batch(engine, model, tokenizer, clips: Sequence[np.ndarray], opti
         # decode_with_fallback: walk the temperature ladder for the clips whose result fails a threshold
         final = [None] * n
         todo = list(active)
+        # the noise of a sampled token is keyed by (seed, clip key, position, token): the key names the recording and its window, so a
+        # clip draws the same tokens whichever clips share its batch (another shard of the run, another batch size)
+        engine.whisper_sample_keys([(clip_ids[i] ^ (2654435761 * (seeks[i] + 1))) & 0x7FFFFFFF for i in range(n)])
         for t in opt.temperature:
             toks, lps, sums = DEC.decode_batch(engine, n_vocab, prompts, begins, rules, sample_len, temperature=float(t),
-                                               seed=opt.seed + int(round(t * 1000)) + 7919 * max(seeks), active=todo, n_text_ctx=n_text_ctx)
+                                               seed=opt.seed + int(round(t * 1000)), active=todo, n_text_ctx=n_text_ctx)
             for i in range(n):
                 if not todo[i]:
                     continue

@@ -20,6 +20,7 @@ PCE_BOTH(int, pce_whisper_align_fetch, (pce_ctx *, int32_t, int32_t *, int32_t *
 PCE_BOTH(int, pce_whisper_align_shape, (pce_ctx *, int32_t, int32_t *, int32_t *))
 PCE_BOTH(int, pce_whisper_align_paths_enqueue, (pce_ctx *, int32_t, int32_t *, int32_t *))
 PCE_BOTH(int, pce_whisper_align_paths_wait, (pce_ctx *, int32_t, int32_t *, int32_t *, int32_t *))
+PCE_BOTH(int, pce_whisper_sample_keys, (pce_ctx *, const int32_t *, int32_t))
 PCE_BOTH(int, pce_whisper_decode_step, (pce_ctx *, const int32_t *, const int32_t *, int32_t, const pce_whisper_decode_rules *, const uint8_t *, int32_t *, float *))
 PCE_BOTH(int, pce_whisper_decode_step_ex, (pce_ctx *, const int32_t *, const int32_t *, const pce_whisper_decode_rules *, const uint8_t *, const pce_whisper_decode_opts *, int32_t *, float *, float *))
 PCE_BOTH(int, pce_whisper_decode_loop, (pce_ctx *, const int32_t *, const int32_t *, const pce_whisper_decode_rules *, const uint8_t *, const pce_whisper_decode_opts *, int32_t, int32_t, int32_t *, float *, int32_t *, float *))
@@ -79,6 +80,7 @@ int pce_whisper_align_paths_wait(pce_ctx *c, int32_t slot, int32_t *path_len, in
 {
     return PCE_FWD(pce_whisper_align_paths_wait, c, slot, path_len, text_idx, time_idx);
 }
+int pce_whisper_sample_keys(pce_ctx *c, const int32_t *keys, int32_t n) { return PCE_FWD(pce_whisper_sample_keys, c, keys, n); }
 int pce_whisper_decode_step(pce_ctx *c, const int32_t *tokens, const int32_t *token_offsets, int32_t sample_begin, const pce_whisper_decode_rules *rules,
                             const uint8_t *vocab_mask, int32_t *next_tokens, float *next_logprobs)
 {

@@ -111,7 +111,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_set_refine", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_levenshtein", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_align_paths_enqueue", "pce_whisper_align_paths_wait", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
+           "pce_dtw", "pce_nw_align", "pce_levenshtein", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_align_paths_enqueue", "pce_whisper_align_paths_wait", "pce_whisper_sample_keys", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_selftest_attention", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
@@ -171,6 +171,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_align_fetch.argtypes = [vp, i32, vp, vp, C.POINTER(i32), vp]
     lib.pce_whisper_align_paths_enqueue.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.pce_whisper_align_paths_wait.argtypes = [vp, i32, vp, vp, vp]
+    lib.pce_whisper_sample_keys.argtypes = [vp, vp, i32]
     lib.pce_bert_load.argtypes = [vp, C.POINTER(BertDims), vp, i64]
     lib.pce_bert_run.argtypes = [vp, vp, vp, i32]
     lib.pce_bert_fetch.argtypes = [vp, i32, vp, vp]
@@ -446,6 +447,14 @@ class ProsodyEngine:
 
     def whisper_num_encoded(self) -> int:
         return getattr(self, "_n_encoded", 0)
+
+    def whisper_sample_keys(self, keys=None):
+        """``pce_whisper_sample_keys``: the ids temperature sampling keys its noise by, one per clip of the encoded batch (None: back to
+        batch positions).  They last until the next :meth:`whisper_encode_run`."""
+        if keys is None or len(keys) == 0:
+            self._check(self._lib.pce_whisper_sample_keys(self._ctx, None, 0)); return
+        k = np.ascontiguousarray(np.asarray(keys, dtype=np.int64) & 0x7FFFFFFF, dtype=np.int32)
+        self._check(self._lib.pce_whisper_sample_keys(self._ctx, k.ctypes.data, int(k.size)))
 
     def selftest_gemm(self, A, B, bias=None, epilogue: int = 0, rows_per_clip: int = 1, vt_sp: int = 0):
         """C = epilogue(A B^T + bias) on the persistent 256 x 256 GEMM kernel; A [M][K], B [N][K] float arrays (rounded to bf16 here) ->

@@ -262,6 +262,48 @@ def test_temperature_ladder_and_thresholds(engine, model_dir):
     assert TR.transcribe_batch(engine, model, tk, clips, opts)[0]["segments"] == []
 
 
+def test_sampled_tokens_do_not_depend_on_the_batch(engine, model_dir):
+    """``pce_whisper_sample_keys``: the noise of a sampled token is keyed by the caller's id of the clip, so a clip draws the same tokens
+    wherever it stands in a batch and whatever it is batched with -- without keys the batch position is the key and the draws move.
+    Then the same through ``transcribe_batch`` with every window pushed to the last temperature of the ladder (the keys are a hash of
+    the clip's samples and the window start): a recording's result is the same alone, first of three and last of three."""
+    root, tk, tdims, enc, dec = model_dir
+    model = CK.load_model("medium", str(root)).load_into(engine)
+    rules = tk.decoding_rules()
+    V = tdims["n_vocab"]
+    clips = [synth.synth_clip(k, seconds=3.0 + k) for k in (1, 2, 3)]
+    sot = list(tk.sot_sequence())
+
+    def sample(order, keys):
+        engine.upload([clips[k] for k in order], 16000)
+        engine.logmel_run(model.dims["n_mels"]); engine.whisper_encode_run()
+        if keys is not None:
+            engine.whisper_sample_keys([keys[k] for k in order])
+        toks, _, _ = DEC.decode_batch(engine, V, [sot] * len(order), [len(sot)] * len(order), rules, 10, temperature=1.0, seed=11)
+        return {k: toks[i] for i, k in enumerate(order)}
+
+    keys = {0: 123456789, 1: 7, 2: 2**31 - 1}
+    a, b, c = sample([0, 1, 2], keys), sample([2, 0, 1], keys), sample([1], keys)
+    assert a == b and c[1] == a[1]
+    p, q = sample([0, 1, 2], None), sample([2, 0, 1], None)
+    assert p != q                                                    # (10 draws from a 50 000-way softmax at temperature 1, three clips)
+    assert sample([0, 1, 2], {0: 0, 1: 1, 2: 2}) == p               # the default key IS the batch position
+    # keys are dropped by the next encoder run, refused for another clip count, and before any encoder run
+    engine.whisper_sample_keys([5, 6, 7])
+    with pytest.raises(E.PceError):
+        engine.whisper_sample_keys([5, 6])
+    engine.whisper_sample_keys(None)
+
+    opts = TR.TranscribeOptions(vad=None, sample_len=10, temperature=(0.0, 1.0), logprob_threshold=0.0, no_speech_threshold=None,
+                                compression_ratio_threshold=None, max_windows=2)
+    strip = lambda r: [(s["tokens"], s["temperature"], [w["text"] for w in s["words"]]) for s in r["segments"]]
+    alone = strip(TR.transcribe_batch(engine, model, tk, [clips[1]], opts)[0])
+    first = strip(TR.transcribe_batch(engine, model, tk, [clips[1], clips[0], clips[2]], opts)[0])
+    last = strip(TR.transcribe_batch(engine, model, tk, [clips[2], clips[0], clips[1]], opts)[2])
+    assert alone and all(t == 1.0 for _, t, _ in alone)
+    assert alone == first == last
+
+
 # ----------------------------------------------------------------------------------------------------- main() and the pipeline steps
 def _assert_aligner_outputs(audio_dir: Path, out: Path, names, gated=()):
     for n in names:

@@ -44,6 +44,9 @@ class OracleEngine:
     def whisper_encode_run(self):
         self.enc = [WO.encoder_forward(w, self.We, self.edims) for w in self.windows]
 
+    def whisper_sample_keys(self, keys=None):
+        self.sample_keys = None if keys is None else list(keys)
+
     def whisper_num_encoded(self):
         return len(self.enc)
 
