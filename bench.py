@@ -361,7 +361,7 @@ def run_rank(args, world, rank, local_rank):
         return rec
 
     def fence():
-        if world > 1:
+        if shard.exchanging():
             dist.barrier()
         torch.cuda.synchronize()
         eng.sync()
@@ -393,8 +393,8 @@ def run_rank(args, world, rank, local_rank):
             prof.update(pe.profile())
         pe.profile_enable(False)
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda" if world == 1 or dist.get_backend() == "nccl" else "cpu")
-    if world > 1:
+    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda" if not shard.exchanging() or dist.get_backend() == "nccl" else "cpu")
+    if shard.exchanging():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
     audio_seconds = args.clips * args.seconds * world * args.steps
@@ -694,7 +694,7 @@ def run_rank(args, world, rank, local_rank):
             "metric": ("audio-seconds/sec prosody+align throughput, 16 kHz French" if wdims
                        else "audio-seconds/sec prosody throughput (no alignment leg), 16 kHz French"),
             "value": audio_seconds / dt, "unit": "audio-seconds/sec (x real-time)",
-            "n_gpus": world, "dist_backend": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_spread": spread,
+            "n_gpus": world, "dist_backend": (dist.get_backend() if shard.exchanging() else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms_spread": spread,
             "timing_note": ("the timed region carries the per-kernel HIP event pairs of the profile (about 0.5 % of a step: --no-profile runs without them)"
                             if not args.no_profile else "no per-kernel events in the timed region"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": f"{eng.whisper_operands} (MFMA legs) + f64 (F0 / LUFS)" if wdims else "f64",
@@ -709,7 +709,7 @@ def run_rank(args, world, rank, local_rank):
     if pe is not eng:
         pe.close()
     eng.close()
-    if world > 1:
+    if shard.exchanging():
         dist.destroy_process_group()
 
 

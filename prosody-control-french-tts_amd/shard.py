@@ -38,6 +38,20 @@ def rank_world():
     return 0, 1
 
 
+def exchanging() -> bool:
+    """True when the collectives of this module really run: a process group exists and has more than one rank -- or exactly one
+    and ``PCE_DIST_WORLD1=1``, the form in which the RCCL code path (device tensors, ``all_gather_into_tensor``, the status
+    all-reduce) can execute on a one-GPU box (RCCL refuses two ranks on one device)."""
+    import os
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or os.environ.get("PCE_DIST_WORLD1") == "1"
+    except Exception:                                                    # noqa: BLE001  (torch absent: single process)
+        return False
+
+
 def local_device() -> int:
     """Device index of this rank under a one-process-per-GPU launcher: ``LOCAL_RANK``, unless ``PCE_RANK_DEVICE`` names the device
     (several ranks sharing ONE GPU -- the only multi-rank form a single-GPU box can run; see :func:`init_from_env`)."""
@@ -50,12 +64,12 @@ def init_from_env():
     Backend "nccl" (= RCCL over xGMI), one rank per GPU.  ``PCE_DIST_BACKEND=gloo`` selects gloo for the SAME code path -- the control
     plane and the one all-gather then travel over host memory; RCCL refuses two ranks on one device, so this (with
     ``PCE_RANK_DEVICE=0``) is how the real engine runs under more than one rank on a one-GPU box.  No process group when WORLD_SIZE
-    is absent or 1.  The reference's parallel driver is the spawn pool of Code/audioPipeline.py:1143-1150."""
+    is absent or 1 -- unless ``PCE_DIST_WORLD1=1`` asks for the one-rank group (:func:`exchanging`).  The reference's parallel driver is the spawn pool of Code/audioPipeline.py:1143-1150."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dev = local_device()
-    if world > 1:
+    if world > 1 or os.environ.get("PCE_DIST_WORLD1") == "1":
         import torch
         import torch.distributed as dist
         backend = os.environ.get("PCE_DIST_BACKEND", "nccl")
@@ -82,7 +96,7 @@ def barrier(ok: bool = True) -> bool:
     group.  A rank must reach this call whether or not its local work raised: see :class:`agreed`."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not exchanging():
         return bool(ok)
     device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
@@ -129,7 +143,7 @@ def allgather_records(local: np.ndarray, counts=None, device=None, failed: bool 
     local = np.ascontiguousarray(local, dtype=np.float64)
     if local.ndim != 2:
         raise ValueError("records must be [n, width]")
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not exchanging():
         if failed:
             raise PeerFailure("rank 0 could not produce its records")
         if counts is not None and int(counts[0]) != local.shape[0]:
