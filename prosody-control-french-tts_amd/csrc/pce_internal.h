@@ -55,6 +55,7 @@ struct pce_ctx {
     // dynamic-LDS opt-ins (hipFuncSetAttribute) done on this context's device, per operand-type build: the implementation file is compiled
     // twice, so every kernel below exists as two distinct functions
     bool attn1w_attr[2] = {false, false};
+    bool xattn_attr[2] = {false, false};  // k_xattn_absorbed's dynamic LDS size has been set (per operand build)
     bool gemm_flat_attr[2][4] = {{false, false, false, false}, {false, false, false, false}};   // k_gemm_flat<EPI>
     bool gemm_few_rows = false;          // set by the incremental decoding step around its launches: k_gemm_skinny is eligible
     bool gemm_skinny = true, gemm_skinny_attr[2][4] = {{false, false, false, false}, {false, false, false, false}};   // PCE_GEMM_SKINNY=0 at pce_create: few-row launches stay on the 128 x 128 kernel
@@ -93,6 +94,7 @@ struct pce_ctx {
     double pi_P[32] = {0};          // PiParams image
     int64_t pi_n_work = 0, pi_n_energy_work = 0;
     int pi_np2 = 1;
+    bool xattn_absorb = true;       // incremental decoding steps: cross-attention from the encoder output (pce_xattn.inc); PCE_XATTN_ABSORB=0: from the K / V^T cache
     bool attn_m16 = false;          // attention on v_mfma_f32_16x16x32 (k_attention_lean16) instead of 32x32x16
     bool pi_long_slices = false;    // some slice has more frames than the in-LDS median sort holds (k_pitch_median_long takes those)
     SliceCache pi_cache;

@@ -357,6 +357,69 @@ def test_cached_decoding_with_long_prompts_agrees(engine):
         assert np.allclose(x[:a], y[:a], atol=0.05)
 
 
+@pytest.mark.parametrize("d,heads,n", [(128, 2, 5), (256, 4, 3), (768, 12, 3), (1024, 16, 2)])
+def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_restatement(d, heads, n):
+    """Incremental decoding steps compute their cross-attention from the encoder output (``pce_xattn.inc``: Q' = q Wk, one pass over E,
+    out = Wv U + bv) instead of from the projected K / V^T cache (``PCE_XATTN_ABSORB=0``: the round-3 kernel).  Two contexts, one per form, the
+    same free-running loop (ragged prompts, a clip that is inactive from the start): the same tokens as far as the restatement's margins
+    decide them, log-probabilities within 0.02 of each other, and -- step by step against the fp32 restatement's filtered log-softmax --
+    the new form at least as close as the K / V form (its operands enter the MFMAs as hi + lo pairs: nothing is rounded that the
+    reference's own fp16 arithmetic keeps)."""
+    import os
+    import prosody_control_french_tts_amd as P
+    from tests.test_whisper_hf_crosscheck import _greedy_gold
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    _, rules = _greedy_gold()
+    edims = dict(n_mels=80, n_ctx=1500, n_state=d, n_head=heads, n_layer=2)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=d, n_head=heads, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=177), WW.greedy_test_decoder_weights(tdims, seed=179)
+    use = [synth.synth_clip(40 + i, seconds=3.0 + i) for i in range(n)]
+    init = _greedy_gold()[0]["initial"].tolist()
+    prompts = [[7, 11 + i, 13][: i % 3 + 1] * (i + 1) + list(init) for i in range(n)]
+    begins = [len(p) for p in prompts]
+    active = [i != 1 for i in range(n)]
+    mask = DEC.vocab_mask(tdims["n_vocab"], rules["suppress_tokens"], rules["blank_tokens"], rules["no_timestamps"])
+    runs = {}
+    for form in ("1", "0"):
+        old = os.environ.get("PCE_XATTN_ABSORB")
+        os.environ["PCE_XATTN_ABSORB"] = form
+        try:
+            eng = P.ProsodyEngine(0)
+        finally:
+            if old is None:
+                os.environ.pop("PCE_XATTN_ABSORB", None)
+            else:
+                os.environ["PCE_XATTN_ABSORB"] = old
+        try:
+            eng.upload(use, 16000); eng.logmel_run(80)
+            eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
+            eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+            toks, lps, _ = DEC.decode_batch(eng, tdims["n_vocab"], prompts, begins, rules, sample_len=12, active=active)
+            # teacher-forced on ONE sequence of tokens (the new form's): each step's log-probability of the token that follows
+            encs = [eng.whisper_encode_fetch(i) for i in range(n)]
+            runs[form] = (toks, lps, encs)
+        finally:
+            eng.close()
+    (ta, la, encs), (tb, lb, _) = runs["1"], runs["0"]
+    assert ta[1] == [] and tb[1] == []
+    err = {"1": [], "0": []}
+    for i in range(n):
+        if not active[i]:
+            continue
+        agree = next((k for k, (x, y) in enumerate(zip(ta[i], tb[i])) if x != y), min(len(ta[i]), len(tb[i])))
+        assert agree >= 3, (i, ta[i], tb[i])
+        assert np.allclose(la[i][:agree], lb[i][:agree], atol=0.02), (i, la[i][:agree], lb[i][:agree])
+        seq = list(prompts[i])
+        for k in range(agree):
+            logits = WO.find_alignment(seq, encs[i], Wd, tdims, 2, 0, want_internal=True)["logits"][-1]
+            f = WO.apply_decoding_rules(logits, seq, begins[i], rules)
+            lsm = f - (np.max(f) + np.log(np.sum(np.exp(f[np.isfinite(f)] - np.max(f)))))
+            err["1"].append(abs(la[i][k] - lsm[ta[i][k]])); err["0"].append(abs(lb[i][k] - lsm[ta[i][k]]))
+            seq.append(ta[i][k])
+    assert max(err["1"]) <= 0.05 and max(err["0"]) <= 0.05, (max(err["1"]), max(err["0"]))
+    assert np.mean(err["1"]) <= 1.25 * np.mean(err["0"]) + 1e-4, (np.mean(err["1"]), np.mean(err["0"]))
+
+
 def test_logmel_windows_of_a_long_recording(engine):
     """Recordings longer than 30 s (segment_ph6 of the demo data runs 37.2 s): the window whisper.transcribe takes at a
     seek position is a slice of the log-mel of the WHOLE recording, clamped with the global maximum."""
