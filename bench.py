@@ -471,7 +471,10 @@ def run_rank(args, world, rank, local_rank):
             pr = {k: dict(v, total_ms=v["total_ms"] * len(reps), launches=v["launches"] * len(reps)) for k, v in pr.items()}
             loop_s = float(np.mean([r[0] for r in reps]))
             d_, L_ = tdims["n_state"], tdims["n_layer"]
-            xkv_bytes = L_ * args.clips * (1500 * d_ * 2 + d_ * 1536 * 2)              # cross K rows + V^T image (key axis padded to 1536) of every layer
+            kv_bytes = L_ * args.clips * (1500 * d_ * 2 + d_ * 1536 * 2)               # cross K rows + V^T image (key axis padded to 1536) of every layer
+            # round 5: an incremental step attends from the encoder output itself (csrc/pce_xattn.inc: E once per layer), unless PCE_XATTN_ABSORB=0
+            absorbed = os.environ.get("PCE_XATTN_ABSORB", "1") != "0" and d_ in (128, 256, 384, 512, 768, 1024) and tdims["n_head"] <= 16
+            xkv_bytes = L_ * args.clips * 1500 * d_ * 2 if absorbed else kv_bytes
             # the loop call = cross K / V projections (once per window) + the prompt's prefix step + N - 1 incremental steps
             xproj_ms = pr.get("k_gemm_flat:xkv", {}).get("total_ms", 0.0) / len(reps)
             step0_ms = pr.get("whisper_decode_step", {}).get("total_ms", 0.0) / len(reps)
@@ -484,8 +487,12 @@ def run_rank(args, world, rank, local_rank):
                           "host_syncs_per_window": 2 + (N - 1) // 4,
                           "roofline": {"bound": "hbm", "bytes_per_step": xkv_bytes, "achieved": xkv_bytes / (inc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": xkv_bytes / (inc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "note": "algorithmic bytes of an incremental step = the cross-attention K rows and V^T of all layers "
-                                               "(read once per step); weights (0.28 GB) and the self-attention cache are not counted"},
+                                       "cross_attention_form": "encoder output (Q' = q Wk, U = sum p E, out = Wv U + bv)" if absorbed else "K / V^T cache",
+                                       "kv_form_bytes_per_step": kv_bytes, "kv_form_equivalent_GBps": kv_bytes / (inc_ms * 1e-3) / 1e9,
+                                       "note": "algorithmic bytes of an incremental step = what its cross-attention has to read once per layer: the encoder "
+                                               "output E (round 5) -- the K rows and V^T of round 3 / 4 were twice that (kv_form_bytes_per_step; "
+                                               "kv_form_equivalent_GBps = those bytes / this step time, for comparison with earlier rounds' lines); weights "
+                                               "(0.28 GB) and the self-attention cache are not counted"},
                           "kernels": {k: {"ms_per_window": v["total_ms"] / len(reps), "launches_per_window": v["launches"] / len(reps)}
                                       for k, v in pr.items() if k in ("k_cross_attn1", "k_gemm_skinny", "k_gemm_bf16", "k_attention_lean", "whisper_decode_loop",
                                                                      "whisper_encoder", "whisper_align", "k_gemm_flat:xkv")}}

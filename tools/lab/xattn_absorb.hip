@@ -32,6 +32,9 @@ template <int D> __device__ __forceinline__ int xa_off(int row, int col8 /* 16-b
 
 __device__ __forceinline__ s16x4 tr_read(unsigned addr) { s16x4 r; asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr)); return r; }
 
+#ifndef CPOL
+#define CPOL 0         // cache policy bits of the LDS-DMA loads (gfx950: 1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef ABL
 #define ABL 0          // ablation bits (timing only, results wrong): 1 no lo-part MFMAs, 2 no U^T product, 4 no DMA, 8 no compute (DMA + barriers only)
 #endif
@@ -88,7 +91,7 @@ __device__ __forceinline__ void xattn_absorbed_body(const XaArgs &A)
         char *slot = smem + (t % NSLOT) * TILE;
 #pragma unroll
         for (int i = 0; i < LPW; i++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (__attribute__((address_space(3))) void *)(slot + 1024 * (wv + 4 * i)), 16, voff[i], (t_lo + t * t_st) * TF * A.e_ld * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (__attribute__((address_space(3))) void *)(slot + 1024 * (wv + 4 * i)), 16, voff[i], (t_lo + t * t_st) * TF * A.e_ld * 2, 0, CPOL);
     };
     int raddr[KS];                                               // row reads: frame n16, d chunk of k-step wv KS + ks
 #pragma unroll
@@ -201,9 +204,9 @@ static float run(const XaArgs &a, int reps, hipStream_t st)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     XaArgs b = a;
     const dim3 grid(a.n * a.nsplit);
-    for (int i = 0; i < 3; i++) { b.flip = i & 1; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); }
+    for (int i = 0; i < 3; i++) { b.flip = (i & 1) & a.flip; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); }
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; i++) { b.flip = i & 1; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); }
+    for (int i = 0; i < reps; i++) { b.flip = (i & 1) & a.flip; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); }
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     b.flip = 0; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); CK(hipStreamSynchronize(st));
@@ -213,7 +216,7 @@ static float run(const XaArgs &a, int reps, hipStream_t st)
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 256, D = argc > 2 ? atoi(argv[2]) : 768, H = D / 64, T = 1500;
-    const int nsplit = argc > 3 ? atoi(argv[3]) : 2;
+    const int nsplit = argc > 3 ? atoi(argv[3]) : 2, flipmode = argc > 4 ? atoi(argv[4]) : 1;
     std::vector<op_t> E((size_t)n * T * D), qh((size_t)n * 16 * D), ql((size_t)n * 16 * D);
     unsigned long long s = 88172645463325252ull;
     auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((s >> 11) * (1.0 / 9007199254740992.0)) * 2.f - 1.f; };
@@ -232,7 +235,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dE, E.data(), E.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dqh, qh.data(), qh.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dql, ql.data(), ql.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dk, klen.data(), n * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dup, 0, up_n * 4)); CK(hipMemset(dml, 0, ml_n * 4));
-    XaArgs a{dE, (int64_t)T * D, D, dqh, dql, dk, nullptr, dup, dml, H, n, 0, nsplit};
+    XaArgs a{dE, (int64_t)T * D, D, dqh, dql, dk, nullptr, dup, dml, H, n, flipmode, nsplit};
     hipStream_t st; CK(hipStreamCreate(&st));
     const int reps = 40;
     float ms = 0;
