@@ -357,8 +357,8 @@ def test_cached_decoding_with_long_prompts_agrees(engine):
         assert np.allclose(x[:a], y[:a], atol=0.05)
 
 
-@pytest.mark.parametrize("d,heads,n", [(128, 2, 5), (256, 4, 3), (768, 12, 3), (1024, 16, 2)])
-def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_restatement(d, heads, n):
+@pytest.mark.parametrize("d,heads,n,ops", [(128, 2, 5, None), (256, 4, 3, None), (384, 6, 2, None), (768, 12, 3, None), (1024, 16, 2, None), (256, 4, 3, "bf16")])
+def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_restatement(d, heads, n, ops):
     """Incremental decoding steps compute their cross-attention from the encoder output (``pce_xattn.inc``: Q' = q Wk, one pass over E,
     out = Wv U + bv) instead of from the projected K / V^T cache (``PCE_XATTN_ABSORB=0``: the round-3 kernel).  Two contexts, one per form, the
     same free-running loop (ragged prompts, a clip that is inactive from the start): the same tokens as far as the restatement's margins
@@ -391,6 +391,8 @@ def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_res
             else:
                 os.environ["PCE_XATTN_ABSORB"] = old
         try:
+            if ops:
+                eng.whisper_set_operands(ops)
             eng.upload(use, 16000); eng.logmel_run(80)
             eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
             eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
@@ -408,7 +410,7 @@ def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_res
             continue
         agree = next((k for k, (x, y) in enumerate(zip(ta[i], tb[i])) if x != y), min(len(ta[i]), len(tb[i])))
         assert agree >= 3, (i, ta[i], tb[i])
-        assert np.allclose(la[i][:agree], lb[i][:agree], atol=0.02), (i, la[i][:agree], lb[i][:agree])
+        assert np.allclose(la[i][:agree], lb[i][:agree], atol=0.1 if ops == "bf16" else 0.02), (i, la[i][:agree], lb[i][:agree])
         seq = list(prompts[i])
         for k in range(agree):
             logits = WO.find_alignment(seq, encs[i], Wd, tdims, 2, 0, want_internal=True)["logits"][-1]
@@ -416,7 +418,8 @@ def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_res
             lsm = f - (np.max(f) + np.log(np.sum(np.exp(f[np.isfinite(f)] - np.max(f)))))
             err["1"].append(abs(la[i][k] - lsm[ta[i][k]])); err["0"].append(abs(lb[i][k] - lsm[ta[i][k]]))
             seq.append(ta[i][k])
-    assert max(err["1"]) <= 0.05 and max(err["0"]) <= 0.05, (max(err["1"]), max(err["0"]))
+    tol = 0.25 if ops == "bf16" else 0.05
+    assert max(err["1"]) <= tol and max(err["0"]) <= tol, (max(err["1"]), max(err["0"]))
     assert np.mean(err["1"]) <= 1.25 * np.mean(err["0"]) + 1e-4, (np.mean(err["1"]), np.mean(err["0"]))
 
 
