@@ -50,22 +50,24 @@ struct XaArgs {
 
 // one workgroup = one (clip, split): 16-frame tiles of E through a ring of NSLOT LDS slots, 4 waves; wave w owns d / 4 of the reduction axis of
 // S^T = E Q'^T (partials summed through LDS) and d / 4 of the columns of U^T = E^T P^T
-template <int D, int NSLOT>
+template <int D, int NSLOT, int G2>
 __device__ __forceinline__ void xattn_absorbed_body(const XaArgs &A)
 {
     constexpr int TF = 16, KS = D / 128, CB = D / 64, LPW = D / 128, TILE = TF * D * 2;   // k-steps / column blocks / DMA instructions per wave; tile bytes
     extern __shared__ __attribute__((aligned(16))) char smem[];                          // NSLOT tiles | 4 x 1 KB of partial S^T
     const int bid = A.flip ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int clip = bid / A.nsplit, split = bid - clip * A.nsplit;
+    const int nsw = A.nsplit / G2;                              // splits at workgroup level; a workgroup's G2 groups of 4 waves take alternate tiles of its range
+    const int clip = bid / nsw, wsplit = bid - clip * nsw;
     if (A.skip && A.skip[clip]) return;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), grp = wv8 >> 2, wv = wv8 & 3;
+    const int split = wsplit * G2 + grp;
     const int n16 = lane & 15, g = lane >> 4;
     const int Sk = A.k_len[clip];
-    const int nt_all = (Sk + TF - 1) / TF, per = (nt_all + A.nsplit - 1) / A.nsplit;
+    const int nt_all = (Sk + TF - 1) / TF, per = (nt_all + nsw - 1) / nsw;
 #ifdef INTERLEAVE                 // (measured: the splits of a clip taking every nsplit-th tile instead of contiguous ranges changes nothing, 124 against 122 us)
     const int t_lo = split, t_st = A.nsplit, nt = nt_all > split ? (nt_all - split + A.nsplit - 1) / A.nsplit : 0; (void)per;
 #else
-    const int t_lo = split * per, t_st = 1, t_hi = min(nt_all, t_lo + per), nt = max(t_hi - t_lo, 0);
+    const int t_lo = wsplit * per, t_st = 1, t_hi = min(nt_all, t_lo + per), nt = max(t_hi - t_lo, 0);
 #endif
     const op_t *eb = A.E + (int64_t)clip * A.e_clip;
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<op_t *>(eb), 0, ((Sk - 1) * A.e_ld + D) * 2, 0x00020000);
@@ -84,36 +86,40 @@ __device__ __forceinline__ void xattn_absorbed_body(const XaArgs &A)
     int voff[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; i++) {
-        const int X = 64 * (wv + 4 * i) + lane, row = X / (D / 8), ch = (X % (D / 8)) ^ xa_swz(row);
+        const int X = 64 * (wv8 + 4 * G2 * i) + lane, row = X / (D / 8), ch = (X % (D / 8)) ^ xa_swz(row);
         voff[i] = (row * A.e_ld + 8 * ch) * 2;
     }
-    auto stage = [&](int t) {
-        char *slot = smem + (t % NSLOT) * TILE;
+    constexpr int NIT = NSLOT / G2;                              // ring depth in iterations (an iteration = G2 consecutive tiles, one per group)
+    auto stage = [&](int it) {
+        char *slot = smem + (it % NIT) * G2 * TILE;
 #pragma unroll
         for (int i = 0; i < LPW; i++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (__attribute__((address_space(3))) void *)(slot + 1024 * (wv + 4 * i)), 16, voff[i], (t_lo + t * t_st) * TF * A.e_ld * 2, 0, CPOL);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (__attribute__((address_space(3))) void *)(slot + 1024 * (wv8 + 4 * G2 * i)), 16, voff[i], (t_lo + it * G2) * TF * A.e_ld * 2, 0, CPOL);
     };
     int raddr[KS];                                               // row reads: frame n16, d chunk of k-step wv KS + ks
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) raddr[ks] = xa_off<D>(n16, 4 * (wv * KS + ks) + g);
     const int q4 = n16 >> 2, p4 = n16 & 3;
-    float *xs = reinterpret_cast<float *>(smem + NSLOT * TILE);
+    float *xs = reinterpret_cast<float *>(smem + NSLOT * TILE) + grp * 1024;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 u[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; cb++) u[cb] = z4;
     float m_run = -1e30f, l_part = 0.f;
-    for (int t = 0; t < NSLOT - 1 && t < nt; t++) stage(t);
-    for (int t = 0; t < nt; t++) {
-        if (NSLOT >= 3 && t + 1 < nt) __builtin_amdgcn_s_waitcnt(0x0F70 | ((NSLOT - 2) * LPW)); else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
+    const int nit = (nt + G2 - 1) / G2;
+    for (int it = 0; it < NIT - 1 && it < nit; it++) stage(it);
+    for (int it = 0; it < nit; it++) {
+        if (NIT >= 3 && it + 1 < nit) __builtin_amdgcn_s_waitcnt(0x0F70 | ((NIT - 2) * LPW)); else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
         __builtin_amdgcn_s_barrier();
-        if (!(ABL & 4) && t + NSLOT - 1 < nt) stage(t + NSLOT - 1);
+        if (!(ABL & 4) && it + NIT - 1 < nit) stage(it + NIT - 1);
         if (ABL & 8) continue;
-        const char *sC = smem + (t % NSLOT) * TILE;
-        const unsigned sbase = lds0 + (unsigned)((t % NSLOT) * TILE);
+        const int t = it * G2 + grp;
+        const bool live = t < nt;                                // (wave-uniform; a group without a tile in the last iteration still meets the barriers)
+        const char *sC = smem + (it % NIT) * G2 * TILE + grp * TILE;
+        const unsigned sbase = lds0 + (unsigned)((it % NIT) * G2 * TILE + grp * TILE);
         // ---- partial S^T over this wave's quarter of d
-        {
+        if (live) {
             f32x4 a = z4;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
@@ -127,6 +133,7 @@ __device__ __forceinline__ void xattn_absorbed_body(const XaArgs &A)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (!live) continue;
         f32x4 sc = z4;
 #pragma unroll
         for (int w2 = 0; w2 < 4; w2++) {                         // (every wave adds in the same order: the same bits everywhere)
@@ -193,23 +200,23 @@ __device__ __forceinline__ void xattn_absorbed_body(const XaArgs &A)
     }
 }
 
-template <int D, int NSLOT>
-__global__ __launch_bounds__(256, 2) void k_xattn_absorbed(XaArgs A) { xattn_absorbed_body<D, NSLOT>(A); }
+template <int D, int NSLOT, int G2>
+__global__ __launch_bounds__(256 * G2, G2 == 1 ? 2 : 1) void k_xattn_absorbed(XaArgs A) { xattn_absorbed_body<D, NSLOT, G2>(A); }
 
-template <int D, int NSLOT>
+template <int D, int NSLOT, int G2 = 1>
 static float run(const XaArgs &a, int reps, hipStream_t st)
 {
-    const size_t lds = (size_t)NSLOT * 16 * D * 2 + 4096;
-    CK(hipFuncSetAttribute((const void *)k_xattn_absorbed<D, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)NSLOT * 16 * D * 2 + 4096 * G2;
+    CK(hipFuncSetAttribute((const void *)k_xattn_absorbed<D, NSLOT, G2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     XaArgs b = a;
-    const dim3 grid(a.n * a.nsplit);
-    for (int i = 0; i < 3; i++) { b.flip = (i & 1) & a.flip; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); }
+    const dim3 grid(a.n * a.nsplit / G2);
+    for (int i = 0; i < 3; i++) { b.flip = (i & 1) & a.flip; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT, G2>), grid, dim3(256 * G2), lds, st, b); }
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; i++) { b.flip = (i & 1) & a.flip; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); }
+    for (int i = 0; i < reps; i++) { b.flip = (i & 1) & a.flip; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT, G2>), grid, dim3(256 * G2), lds, st, b); }
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-    b.flip = 0; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT>), grid, dim3(256), lds, st, b); CK(hipStreamSynchronize(st));
+    b.flip = 0; hipLaunchKernelGGL((k_xattn_absorbed<D, NSLOT, G2>), grid, dim3(256 * G2), lds, st, b); CK(hipStreamSynchronize(st));
     return ms / reps;
 }
 
@@ -241,7 +248,9 @@ int main(int argc, char **argv)
     float ms = 0;
     if (D == 384) ms = run<384, 3>(a, reps, st);
     else if (D == 512) ms = run<512, 3>(a, reps, st);
-#ifdef NSL
+#ifdef GRP2
+    else if (D == 768) ms = run<768, 6, 2>(a, reps, st);
+#elif defined(NSL)
     else if (D == 768) ms = run<768, NSL>(a, reps, st);
 #else
     else if (D == 768) ms = run<768, 3>(a, reps, st);
