@@ -55,7 +55,7 @@ struct pce_ctx {
     // dynamic-LDS opt-ins (hipFuncSetAttribute) done on this context's device, per operand-type build: the implementation file is compiled
     // twice, so every kernel below exists as two distinct functions
     bool attn1w_attr[2] = {false, false};
-    bool xattn_attr[2] = {false, false};  // k_xattn_absorbed's dynamic LDS size has been set (per operand build)
+    unsigned xattn_attr[2] = {0u, 0u};    // k_xattn_absorbed<d, slots>: bit per instantiation whose dynamic LDS size has been set (per operand build)
     bool gemm_flat_attr[2][4] = {{false, false, false, false}, {false, false, false, false}};   // k_gemm_flat<EPI>
     bool gemm_few_rows = false;          // set by the incremental decoding step around its launches: k_gemm_skinny is eligible
     bool gemm_skinny = true, gemm_skinny_attr[2][4] = {{false, false, false, false}, {false, false, false, false}};   // PCE_GEMM_SKINNY=0 at pce_create: few-row launches stay on the 128 x 128 kernel

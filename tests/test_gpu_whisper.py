@@ -423,6 +423,24 @@ def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_res
     assert np.mean(err["1"]) <= 1.25 * np.mean(err["0"]) + 1e-4, (np.mean(err["1"]), np.mean(err["0"]))
 
 
+def test_one_context_decodes_models_of_different_widths_in_turn(engine):
+    """``k_xattn_absorbed<d, slots>`` is one function per width, each with its own dynamic-LDS attribute (68 KB at d = 1024: above the default
+    limit): a context that has decoded with one width must still be able to decode with another (the attribute is tracked per instantiation)."""
+    from tests.test_whisper_hf_crosscheck import _greedy_gold
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    _, rules = _greedy_gold()
+    init = _greedy_gold()[0]["initial"].tolist()
+    use = [synth.synth_clip(60 + i, seconds=2.0) for i in range(2)]
+    for d, heads in ((128, 2), (1024, 16), (256, 4), (768, 12)):
+        edims = dict(n_mels=80, n_ctx=1500, n_state=d, n_head=heads, n_layer=1)
+        tdims = dict(n_vocab=300, n_text_ctx=96, n_state=d, n_head=heads, n_layer=1)
+        engine.upload(use, 16000); engine.logmel_run(80)
+        engine.whisper_load(edims, WW.pack(WW.synthetic_weights(edims, seed=5), edims)); engine.whisper_encode_run()
+        engine.whisper_decoder_load(tdims, WW.pack_decoder(WW.greedy_test_decoder_weights(tdims, seed=6), tdims))
+        toks, lps, _ = DEC.decode_batch(engine, tdims["n_vocab"], [list(init)] * 2, [len(init)] * 2, rules, sample_len=5)
+        assert all(1 <= len(t) <= 5 for t in toks) and all(np.isfinite(l).all() for l in lps)
+
+
 def test_logmel_windows_of_a_long_recording(engine):
     """Recordings longer than 30 s (segment_ph6 of the demo data runs 37.2 s): the window whisper.transcribe takes at a
     seek position is a slice of the log-mel of the WHOLE recording, clamped with the global maximum."""
