@@ -123,6 +123,7 @@ pce_ctx *pce_create(int device, void *stream, char *err, size_t errlen)
     c->gemm_skinny = !(getenv("PCE_GEMM_SKINNY") && atoi(getenv("PCE_GEMM_SKINNY")) == 0);
     // attention on v_mfma_f32_16x16x32 (round 5, default: 30.5 -> 29.6 ms per C3 step on one box, profiles/r05); PCE_ATTN_M16=0: the 32x32x16 kernel
     c->attn_m16 = !(getenv("PCE_ATTN_M16") && atoi(getenv("PCE_ATTN_M16")) == 0);
+    c->self_rows = !(getenv("PCE_SELF_ROWS") && atoi(getenv("PCE_SELF_ROWS")) == 0);
     c->attn_nt = !(getenv("PCE_ATTN_NT") && atoi(getenv("PCE_ATTN_NT")) == 0);
     c->xattn_absorb = !(getenv("PCE_XATTN_ABSORB") && atoi(getenv("PCE_XATTN_ABSORB")) == 0);
     {

@@ -95,6 +95,7 @@ struct pce_ctx {
     int64_t pi_n_work = 0, pi_n_energy_work = 0;
     int pi_np2 = 1;
     bool xattn_absorb = true;       // incremental decoding steps: cross-attention from the encoder output (pce_xattn.inc); PCE_XATTN_ABSORB=0: from the K / V^T cache
+    bool self_rows = true;          // incremental steps' self-attention on row-major K / V caches (k_self_attn1w); PCE_SELF_ROWS=0: k_cross_attn1w on K rows + V^T
     bool attn_nt = true;            // single-query-block attention launches stream K / V^T with the non-temporal policy (PCE_ATTN_NT=0: default policy)
     bool attn_m16 = false;          // attention on v_mfma_f32_16x16x32 (k_attention_lean16) instead of 32x32x16
     bool pi_long_slices = false;    // some slice has more frames than the in-LDS median sort holds (k_pitch_median_long takes those)
