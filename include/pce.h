@@ -279,7 +279,7 @@ int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_
  *              mlp_ln.w,b  mlp.0.w,b  mlp.2.w,b
  *   ln.w,b */
 typedef struct pce_whisper_text_dims {
-    int32_t n_vocab, n_text_ctx /* <= 448 */, n_state, n_head, n_layer;
+    int32_t n_vocab /* <= 52224 */, n_text_ctx /* <= 448 */, n_state, n_head, n_layer;
 } pce_whisper_text_dims;
 int pce_whisper_decoder_load(pce_ctx *ctx, const pce_whisper_text_dims *dims, const float *weights, int64_t n_floats);
 /* tokens: concatenated per clip (token_offsets[n_clips+1]); num_frames: mel frames of real audio per clip;
