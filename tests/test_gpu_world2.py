@@ -293,3 +293,66 @@ def test_run_all_with_the_real_engine_at_world2_and_a_rank_local_failure(tmp_pat
             return
         notes.append([line for o in outs for line in o.splitlines() if "AssertionError" in line][-1:] or [outs[0][-300:]])
     assert False, "eight attempts failed:\n" + "\n".join(str(n) for n in notes) + "\n" + outs[0][-6000:]
+
+
+_ALIGN_AB = r'''
+import json, logging, os, sys
+import numpy as np
+root, base = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+from pathlib import Path
+from prosody_control_french_tts_amd import tagger as T
+from prosody_control_french_tts_amd.Aligners import use_whisper_timestamped as A
+from tests.test_gpu_c5 import WORDS, write_wav
+from tests.test_gpu_aligner import write_model_dir
+base = Path(base)
+logging.basicConfig(level=logging.ERROR)
+z = np.load(Path(root) / "tests" / "golden" / "demo_full.npz")
+rate = int(z["rate"])
+names = sorted((k for k in z.files if k != "rate"), key=T.segment_sort_key)
+for k, n in enumerate(names):
+    write_wav(base / "audio" / f"segment_ph{k + 1}.wav", z[n], rate)
+write_model_dir(base / "whisper_dir", merges=WORDS, word_gain=3.0, eot_gain=0.3)
+os.environ["PCE_WHISPER_DIR"] = str(base / "whisper_dir")
+A.main(str(base / "audio"), str(base / "out"), whisper_model="medium", device="cuda")
+print("ALIGN OK")
+'''
+
+
+def test_aligner_files_do_not_depend_on_the_decoding_kernels(tmp_path):
+    """The "Align+Transcribe" step over the reference's ten demo recordings (2.9-37.2 s: two Whisper windows, VAD, free-running decoding, forced
+    alignment) in two fresh processes: the round-5 decoding kernels (cross-attention from the encoder output, row-major self-attention caches)
+    against the round-3 / 4 ones (``PCE_XATTN_ABSORB=0 PCE_SELF_ROWS=0``).  Every TextGrid and transcription is text-identical; the raw JSON
+    holds the same words with the same times, confidences within 0.002 (they are probabilities of the same tokens computed through different
+    sums)."""
+    outs = {}
+    for tag, extra in (("new", {}), ("old", {"PCE_XATTN_ABSORB": "0", "PCE_SELF_ROWS": "0"})):
+        base = tmp_path / tag
+        base.mkdir()
+        script = base / "run.py"
+        script.write_text(_ALIGN_AB)
+        env = _env(**extra)
+        env.pop("PCE_DIST_BACKEND", None); env.pop("PCE_RANK_DEVICE", None)
+        r = subprocess.run([sys.executable, str(script), ROOT, str(base)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ALIGN OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        outs[tag] = base
+    def files(b, sub, suffix):
+        return sorted(p for p in (b / sub).glob("*" + suffix))
+    tg_new, tg_old = files(outs["new"], "out", ".TextGrid"), files(outs["old"], "out", ".TextGrid")
+    assert len(tg_new) == 10 and [p.name for p in tg_new] == [p.name for p in tg_old]
+    for a, b in zip(tg_new, tg_old):
+        assert a.read_text(encoding="utf-8") == b.read_text(encoding="utf-8"), a.name
+    for a, b in zip(files(outs["new"], "out_transcription", ".txt"), files(outs["old"], "out_transcription", ".txt")):
+        assert a.read_text(encoding="utf-8") == b.read_text(encoding="utf-8"), a.name
+    n_words = 0
+    for a, b in zip(files(outs["new"], "out_raw_json", ".raw.json"), files(outs["old"], "out_raw_json", ".raw.json")):
+        ja, jb = json.loads(a.read_text(encoding="utf-8")), json.loads(b.read_text(encoding="utf-8"))
+        assert ja["text"] == jb["text"] and len(ja["segments"]) == len(jb["segments"]), a.name
+        for sa, sb in zip(ja["segments"], jb["segments"]):
+            assert sa["tokens"] == sb["tokens"] and (sa["start"], sa["end"]) == (sb["start"], sb["end"]), a.name
+            assert [(w["text"], w["start"], w["end"]) for w in sa["words"]] == [(w["text"], w["start"], w["end"]) for w in sb["words"]], a.name
+            for wa, wb in zip(sa["words"], sb["words"]):
+                assert abs(wa["confidence"] - wb["confidence"]) <= 0.002, (a.name, wa, wb)
+                n_words += 1
+    assert n_words > 50
+
