@@ -489,9 +489,10 @@ def run_rank(args, world, rank, local_rank):
                                        "unit": "GB/s", "frac": xkv_bytes / (inc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "cross_attention_form": "encoder output (Q' = q Wk, U = sum p E, out = Wv U + bv)" if absorbed else "K / V^T cache",
                                        "kv_form_bytes_per_step": kv_bytes, "kv_form_equivalent_GBps": kv_bytes / (inc_ms * 1e-3) / 1e9,
+                                       "kv_form_equivalent_frac": kv_bytes / (inc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "note": "algorithmic bytes of an incremental step = what its cross-attention has to read once per layer: the encoder "
                                                "output E (round 5) -- the K rows and V^T of round 3 / 4 were twice that (kv_form_bytes_per_step; "
-                                               "kv_form_equivalent_GBps = those bytes / this step time, for comparison with earlier rounds' lines); weights "
+                                               "kv_form_equivalent_GBps / _frac = those bytes / this step time, for comparison with earlier rounds' `frac`); weights "
                                                "(0.28 GB) and the self-attention cache are not counted"},
                           "kernels": {k: {"ms_per_window": v["total_ms"] / len(reps), "launches_per_window": v["launches"] / len(reps)}
                                       for k, v in pr.items() if k in ("k_cross_attn1", "k_gemm_skinny", "k_gemm_bf16", "k_attention_lean", "whisper_decode_loop",
