@@ -423,6 +423,52 @@ def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_res
     assert np.mean(err["1"]) <= 1.25 * np.mean(err["0"]) + 1e-4, (np.mean(err["1"]), np.mean(err["0"]))
 
 
+@pytest.mark.parametrize("n", [130, 520])
+def test_frame_splits_of_the_encoder_output_cross_attention(n):
+    """The (clip, split) workgroups of ``k_xattn_absorbed`` come in 8 / 4 / 2 / 1 splits of the frames per clip (fewer than 128 / 256 / 512 clips, more):
+    the 4-split and the 1-split forms, which the other tests' batch sizes do not reach, against the K / V-form kernels on the same batch -- the same
+    tokens, log-probabilities within 0.02."""
+    import os
+    import prosody_control_french_tts_amd as P
+    from tests.test_whisper_hf_crosscheck import _greedy_gold
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    _, rules = _greedy_gold()
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=1)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=277), WW.greedy_test_decoder_weights(tdims, seed=279)
+    base = [synth.synth_clip(80 + i, seconds=1.0 + 0.25 * (i % 5)) for i in range(13)]
+    use = [base[i % 13] for i in range(n)]
+    init = _greedy_gold()[0]["initial"].tolist()
+    runs = {}
+    for form in ("1", "0"):
+        old = {k: os.environ.get(k) for k in ("PCE_XATTN_ABSORB", "PCE_SELF_ROWS")}
+        os.environ["PCE_XATTN_ABSORB"] = form; os.environ["PCE_SELF_ROWS"] = form
+        try:
+            eng = P.ProsodyEngine(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        try:
+            eng.upload(use, 16000); eng.logmel_run(80)
+            eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
+            eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+            runs[form] = DEC.decode_batch(eng, tdims["n_vocab"], [list(init)] * n, [len(init)] * n, rules, sample_len=8)[:2]
+        finally:
+            eng.close()
+    (ta, la), (tb, lb) = runs["1"], runs["0"]
+    same = 0
+    for i in range(n):
+        agree = next((k for k, (x, y) in enumerate(zip(ta[i], tb[i])) if x != y), min(len(ta[i]), len(tb[i])))
+        assert agree >= 3, (i, ta[i], tb[i])
+        assert np.allclose(la[i][:agree], lb[i][:agree], atol=0.02), (i, la[i][:agree], lb[i][:agree])
+        same += ta[i] == tb[i]
+        assert ta[i] == ta[i % 13] and np.allclose(la[i], la[i % 13], atol=1e-6)      # the same recording decodes the same wherever it stands in the batch
+    assert same >= 0.9 * n
+
+
 def test_one_context_decodes_models_of_different_widths_in_turn(engine):
     """``k_xattn_absorbed<d, slots>`` is one function per width, each with its own dynamic-LDS attribute (68 KB at d = 1024: above the default
     limit): a context that has decoded with one width must still be able to decode with another (the attribute is tracked per instantiation)."""
