@@ -166,21 +166,28 @@ def spawn_ranks(n, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=600 if rc == 0 else 20)
-        except subprocess.TimeoutExpired:
-            p.kill()
-        rc = rc or p.returncode
-    sys.stdout.write(out0)
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # all ranks are watched together: once one has FAILED its peers get 20 s to leave their collectives (shard.init_from_env bounds
+        # every wait, PCE_DIST_TIMEOUT_S) and are then ended -- a dead rank never leaves the launcher waiting on the others
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.returncode not in (None, 0) for p in procs):
+                failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > 20.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(0.1)
+        rc = next((p.returncode for p in procs if p.returncode), 0)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return rc
 
@@ -689,6 +696,13 @@ def run_rank(args, world, rank, local_rank):
                 if k0.get("achieved_tflops") and k0["kernel"] == "k_pitch_frames":
                     roofline.update({"achieved_tflops_f64": k0["achieved_tflops"], "peak_tflops_f64": FP64_VECTOR_PEAK_TFLOPS,
                                      "frac_f64": k0["achieved_tflops"] / FP64_VECTOR_PEAK_TFLOPS})
+        if roofline is not None and framing and "kernels" in framing:
+            # north_star's framing-kernel figure INSIDE `roofline` (the driver's record keeps `roofline`; a top-level extra key it does not)
+            fk = framing["kernels"]
+            roofline["framing_hbm"] = {"frac": framing["frac"], "min_frac": framing["min_frac"], "bytes": sum(k["algorithmic_bytes"] for k in fk.values()),
+                                       "k_energy_GBps": fk["k_energy"]["achieved"], "k_frame_energy_GBps": fk["k_frame_energy"]["achieved"],
+                                       "k_energy_frac": fk["k_energy"]["frac"], "k_frame_energy_frac": fk["k_frame_energy"]["frac"],
+                                       "peak_GBps": HBM_PEAK_GBS, "clips": args.framing_clips}
         floor = None
         if wdims:
             floor_ms = flop / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3

@@ -8,6 +8,16 @@
 #include <vector>
 #include "pce.h"
 
+// A kernel marked PCE_NO_PK_F32 is compiled without packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Why (round 6,
+// profiles/r06/multiprocess_glitch.txt, tools/lab/pk_victim.hip): on the MI355X boxes of this pool a packed fp32 instruction whose low result lane
+// reads src0's LOW half and src1's HIGH half (op_sel:[0,1]) returns wrong values in lanes 48..63 while another wave on the same SIMD executes MFMA.
+// The compiler forms exactly that selection for complex products and for pair sums; tools/isa_guard.py refuses a library that holds one.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PCE_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define PCE_NO_PK_F32                                    /* (the host pass of the same source: an x86 target knows no such feature) */
+#endif
+
 // Growable device buffer owned by the context.
 struct DevBuf {
     void *p = nullptr;

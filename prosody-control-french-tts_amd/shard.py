@@ -78,11 +78,26 @@ def init_from_env():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(dev)
+        # A bounded wait in every collective (and in the rendezvous itself): the reference's pool hands back ``(ok, name)`` per voice and
+        # ends (Code/audioPipeline.py:1111-1119, 1150-1154); a rank whose peer has died must end too -- with the default (gloo: 30 minutes,
+        # RCCL: 10) the survivor sits inside its next status barrier for that long.  The longest legitimate wait is the slowest rank's
+        # rank-local section of ONE step (every section is left through ``agreed``), so the bound is generous and adjustable.
+        from datetime import timedelta
+        timeout = timedelta(seconds=collective_timeout_s())
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev), timeout=timeout)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
     return rank, world, dev
+
+
+def collective_timeout_s() -> int:
+    """Seconds a rank waits for its peers inside one collective before it raises: ``PCE_DIST_TIMEOUT_S`` (default 300)."""
+    import os
+    t = int(os.environ.get("PCE_DIST_TIMEOUT_S", "300"))
+    if t <= 0:
+        raise ValueError(f"PCE_DIST_TIMEOUT_S={t}: a positive number of seconds")
+    return t
 
 
 class PeerFailure(RuntimeError):

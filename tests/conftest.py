@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """tests/test_gpu_world2.py runs FIRST: its tests start several rank processes on the one GPU, and this (parent) process must not hold an
+    engine context of its own beside them -- the session ``engine`` below is created by the first test that asks for it, i.e. after them."""
+    first = [it for it in items if it.nodeid.startswith("tests/test_gpu_world2.py") or "/test_gpu_world2.py" in it.nodeid]
+    if first:
+        rest = [it for it in items if it not in first]
+        items[:] = first + rest
+
+
 @pytest.fixture(scope="session")
 def engine():
     """One libpce context on cuda:0 for the whole GPU session (fails loudly without a GPU)."""

@@ -14,6 +14,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("operands", ["fp16", "bf16"])
 def test_encoder_and_decoding_loop_repeat_bit_for_bit(operands):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_repeat.py"), "3", operands], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_repeat.py"), "3", operands], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 differ from the first" in r.stdout
+
+
+def test_three_processes_on_one_device_repeat_bit_for_bit():
+    """The reference's shipped default is several worker processes on ONE GPU (/root/reference config.yaml:57-58 ``multiprocessing: True,
+    num_processes: 5``; pool at Code/audioPipeline.py:1148-1150).  Three fresh processes at once, each with its own engine context on cuda:0,
+    repeat log-mel -> encoder -> decoding loop -> alignment 150 times on a resident batch; every stage of every repetition must equal the
+    process's own first one.  Until round 6 a frame of a clip's log-mel (and everything downstream) differed in 5-10 % of the repetitions:
+    packed fp32 instructions with op_sel:[0,1] go wrong in lanes 48..63 while a neighbour wave on the SIMD executes MFMA
+    (profiles/r06/multiprocess_glitch.txt); the kernels that held them (log-mel, STFT, the fused query projection) no longer do
+    (tools/isa_guard.py keeps it that way)."""
+    env = dict(os.environ, PROBE_PAR="3")
+    for k in ("PROBE_STAGES", "PROBE_ROLES", "PROBE_CU_MASKS", "HSA_CU_MASK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lab", "race_probe.py"), "150"], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("three probe processes: no result within 240 s\n" + str(e.stdout)[-2000:] + str(e.stderr)[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if "iterations 150" in l]
+    assert len(lines) == 3, r.stdout[-3000:]
+    assert all(l.rstrip().endswith("stages that ever differed from iteration 0: none") for l in lines), "\n".join(lines)
+
+
+def test_prosody_kernels_beside_the_encoder_of_other_processes():
+    """The STFT-dB transform (packed fp32 with operand-select modifiers, written by hand) was the other victim: one process repeats the prosody
+    kernels while two neighbours run only the Whisper encoder (MFMA) on the same device."""
+    env = dict(os.environ, PROBE_PAR="3", PROBE_ROLES="c2;enc;enc")
+    for k in ("PROBE_STAGES", "PROBE_CU_MASKS", "HSA_CU_MASK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lab", "race_probe.py"), "400"], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("probe processes: no result within 240 s\n" + str(e.stdout)[-2000:] + str(e.stderr)[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if "iterations 400" in l]
+    assert len(lines) == 3 and all(l.rstrip().endswith(": none") for l in lines), r.stdout[-3000:]

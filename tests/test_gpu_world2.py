@@ -25,39 +25,53 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+RUN_TIMEOUT_S = 240         # every child process of this file: one bound, the same treatment for a timeout and for a failed assertion
+PAIR_BUDGET_S = 150         # a pair of rank processes, start to finish
+
+
 def _env(**kw):
-    env = dict(os.environ, PCE_DIST_BACKEND="gloo", PCE_RANK_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # PCE_DIST_TIMEOUT_S: a rank whose peer has gone waits this long inside its next collective (shard.init_from_env), not gloo's 30 minutes
+    env = dict(os.environ, PCE_DIST_BACKEND="gloo", PCE_RANK_DEVICE="0", PCE_DIST_TIMEOUT_S="60",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(kw)
     return env
 
 
+def _tail(text, n=3000):
+    if isinstance(text, bytes):
+        text = text.decode(errors="replace")
+    return (text or "")[-n:]
+
+
+def _run(cmd, env, what):
+    """One child process, bounded: a timeout fails the test the way a non-zero exit does, with the child's output."""
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=RUN_TIMEOUT_S)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail(f"{what}: no result within {RUN_TIMEOUT_S} s\n--- stdout\n{_tail(e.stdout)}\n--- stderr\n{_tail(e.stderr)}")
+    assert r.returncode == 0, f"{what}: exit {r.returncode}\n--- stdout\n{_tail(r.stdout)}\n--- stderr\n{_tail(r.stderr)}"
+    return r
+
+
+def _json_line(r, what):
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"{what}: {len(lines)} JSON lines\n{_tail(r.stdout)}"
+    return json.loads(lines[0])
+
+
 def test_bench_two_ranks_one_device_records_equal_one_rank(tmp_path):
-    for attempt in range(3):                        # (attempts: see the note on GPU oversubscription in the test below)
-        try:
-            _bench_two_ranks(tmp_path / f"a{attempt}")
-            return
-        except AssertionError:
-            if attempt == 2:
-                raise
-
-
-def _bench_two_ranks(tmp_path):
-    tmp_path.mkdir()
-    common = ["--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-clips", "0", "--streamed-steps", "0"]
-    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "64", "--dump-records", str(tmp_path / "w2.npy")] + common,
-                         env=_env(), capture_output=True, text=True, timeout=900)
-    assert two.returncode == 0, two.stdout[-3000:] + two.stderr[-3000:]
-    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, two.stdout[-3000:]
-    j2 = json.loads(lines[0])
+    """ONE attempt: the gathered records of two ranks on one device equal a one-rank run's bit for bit."""
+    common = ["--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-clips", "0", "--streamed-steps", "0", "--framing-clips", "0"]
+    two = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "64", "--dump-records", str(tmp_path / "w2.npy")] + common,
+               _env(), "bench.py --gpus 2")
+    j2 = _json_line(two, "bench.py --gpus 2")
     assert j2["n_gpus"] == 2 and j2["dist_backend"] == "gloo" and j2["scaling"] == "weak" and j2["cpu_baseline"] is None
     assert j2["config"]["clips_per_gpu"] == 64 and j2["value"] > 0 and j2["roofline"] is not None
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "128", "--dump-records", str(tmp_path / "w1.npy")] + common,
-                         env=_env(), capture_output=True, text=True, timeout=900)
-    assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
-    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    one = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "128", "--dump-records", str(tmp_path / "w1.npy")] + common,
+               _env(), "bench.py --gpus 1")
+    j1 = _json_line(one, "bench.py --gpus 1")
     assert j1["n_gpus"] == 1 and j1["dist_backend"] is None
     r2, r1 = np.load(tmp_path / "w2.npy"), np.load(tmp_path / "w1.npy")
     assert r2.shape == r1.shape == (128, 7)
@@ -108,22 +122,18 @@ def test_rccl_code_path_runs_with_one_rank(tmp_path):
                MASTER_PORT=str(29600 + os.getpid() % 200))
     script = tmp_path / "rccl1.py"
     script.write_text(_RCCL1)
-    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "RCCL1 OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    r = _run([sys.executable, str(script), ROOT], env, "one-rank RCCL group")
+    assert "RCCL1 OK" in r.stdout, _tail(r.stdout) + _tail(r.stderr)
     common = ["--workload", "c2", "--steps", "3", "--warmup", "1", "--cpu-clips", "0", "--streamed-steps", "0", "--clips", "64", "--framing-clips", "0"]
     # the driver's own launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
     # --gpus N ...`) with N = 1: the launcher sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
-    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29800 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "1",
-                        "--dump-records", str(tmp_path / "rccl.npy")] + common,
-                       env=_env(PCE_DIST_BACKEND="nccl", PCE_DIST_WORLD1="1"), capture_output=True, text=True, timeout=900)
-    assert a.returncode == 0, a.stdout[-3000:] + a.stderr[-3000:]
-    ja = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][0])
+    a = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", str(29800 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+              "--dump-records", str(tmp_path / "rccl.npy")] + common, _env(PCE_DIST_BACKEND="nccl", PCE_DIST_WORLD1="1"), "bench.py under torch.distributed.run")
+    ja = _json_line(a, "bench.py under torch.distributed.run")
     assert ja["n_gpus"] == 1 and ja["dist_backend"] == "nccl" and ja["value"] > 0
-    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-records", str(tmp_path / "plain.npy")] + common,
-                       env=_env(), capture_output=True, text=True, timeout=900)
-    assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
-    assert json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][0])["dist_backend"] is None
+    b = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-records", str(tmp_path / "plain.npy")] + common, _env(), "bench.py")
+    assert _json_line(b, "bench.py")["dist_backend"] is None
     assert np.load(tmp_path / "rccl.npy").tobytes() == np.load(tmp_path / "plain.npy").tobytes()
 
 
@@ -260,39 +270,42 @@ print("rank", rank, "ok")
 '''
 
 
-def _run_pair(tmp_path, attempt):
-    base = tmp_path / f"attempt{attempt}"
+def _run_pair(base):
+    """Two fresh rank processes, watched TOGETHER: the moment one exits non-zero its peer gets 10 s to fail on its own (PeerFailure, or the
+    bounded wait of shard.init_from_env) and is then ended; the pair as a whole has PAIR_BUDGET_S.  -> (ok, [output of rank 0, of rank 1])"""
+    import time
     base.mkdir()
     script = base / "w2.py"
     script.write_text(_WORKER)
-    port = str(29400 + (os.getpid() + 7 * attempt) % 140)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(base)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                              env=_env()) for r in range(2)]
+    port = str(29400 + os.getpid() % 140)
+    logs = [open(base / f"rank{r}.log", "w+") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, str(base)], stdout=logs[r], stderr=subprocess.STDOUT, env=_env())
+             for r in range(2)]
+    t0 = time.monotonic()
+    failed_at, verdict = None, ""
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        if failed_at is None and any(p.returncode not in (None, 0) for p in procs):
+            failed_at = now
+        if (failed_at is not None and now - failed_at > 10.0) or now - t0 > PAIR_BUDGET_S:
+            verdict = f"ended by the test after {now - t0:.0f} s ({'peer failed' if failed_at is not None else 'budget of %d s spent' % PAIR_BUDGET_S})"
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.1)
     outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=900)[0].decode())
-        except subprocess.TimeoutExpired:
-            p.kill(); outs.append("timeout: " + p.communicate()[0].decode())
+    for f in logs:
+        f.seek(0); outs.append(f.read()); f.close()
     ok = all(p.returncode == 0 and f"rank {r} ok" in o for r, (p, o) in enumerate(zip(procs, outs)))
+    if not ok:
+        outs = [f"[exit {p.returncode}{'; ' + verdict if verdict else ''}]\n{o}" for p, o in zip(procs, outs)]
     return ok, outs
 
 
 def test_run_all_with_the_real_engine_at_world2_and_a_rank_local_failure(tmp_path):
-    """The comparison with the world-1 run is EXACT (text for text); the pair of ranks gets up to eight attempts.  Why attempts: two (or more)
-    processes time-slicing ONE GPU are outside the deployment model (one process per GPU) and on this pool that oversubscription makes
-    LDS-heavy kernels glitch now and then -- rocFFT under plain ``torch.stft`` included (profiles/r05/multiprocess_glitch.txt: a single frame of
-    a log-mel spectrogram off in 1 of ~30 runs with three processes on the device, never with one).  A real dependence on the rank count --
-    the batch-size-dependent GEMM choice this test found in round 5 -- differs on EVERY attempt and still fails; a glitch does not repeat."""
-    notes = []
-    for attempt in range(8):
-        ok, outs = _run_pair(tmp_path, attempt)
-        if ok:
-            if attempt:
-                print(f"passed on attempt {attempt + 1}; earlier attempts: {notes}")
-            return
-        notes.append([line for o in outs for line in o.splitlines() if "AssertionError" in line][-1:] or [outs[0][-300:]])
-    assert False, "eight attempts failed:\n" + "\n".join(str(n) for n in notes) + "\n" + outs[0][-6000:]
+    """ONE attempt, and the comparison with the world-1 run is EXACT (text for text).  On failure both ranks' output is in the report."""
+    ok, outs = _run_pair(tmp_path / "pair")
+    assert ok, "\n".join(f"===== rank {r} (last 3000 characters)\n{_tail(o)}" for r, o in enumerate(outs))
 
 
 _ALIGN_AB = r'''
@@ -333,8 +346,8 @@ def test_aligner_files_do_not_depend_on_the_decoding_kernels(tmp_path):
         script.write_text(_ALIGN_AB)
         env = _env(**extra)
         env.pop("PCE_DIST_BACKEND", None); env.pop("PCE_RANK_DEVICE", None)
-        r = subprocess.run([sys.executable, str(script), ROOT, str(base)], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "ALIGN OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        r = _run([sys.executable, str(script), ROOT, str(base)], env, f"Align+Transcribe, {tag} kernels")
+        assert "ALIGN OK" in r.stdout, _tail(r.stdout) + _tail(r.stderr)
         outs[tag] = base
     def files(b, sub, suffix):
         return sorted(p for p in (b / sub).glob("*" + suffix))
