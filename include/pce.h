@@ -41,9 +41,13 @@ extern "C" {
  * changes of observable defaults:  1 = round 4's default operand mode (fp16 operands + fp16 residual stream), decode loop without the
  * n_text_ctx pre-check;  2 = round 5: pce_levenshtein, pce_whisper_align_paths_enqueue / _wait, no frame limit in pce_pitch_run, the 256 x 256
  * GEMM for every batch size (a clip's Whisper results no longer depend on what it is batched with), unknown PCE_WHISPER_OPERANDS rejected,
- * pce_whisper_sample_keys (temperature sampling keyed by the caller's clip ids instead of batch positions). */
+ * pce_whisper_sample_keys (temperature sampling keyed by the caller's clip ids instead of batch positions);  3 = round 6: the encoder-output
+ * cross-attention of a decoding step always cuts a clip's frames into the same four ranges (minor 2's promise now holds for every batch size: the
+ * round-5 kernel cut them by the number of workgroups per clip, which followed the batch size), pce_whisper_align_paths_enqueue on a slot that
+ * still holds an un-waited fetch is PCE_E_STATE, and no kernel carries the packed fp32 operand selection that returns wrong lanes beside MFMA waves
+ * of other streams / contexts / processes (results no longer depend on what else runs on the device: tools/isa_guard.py). */
 #define PCE_API_VERSION 1
-#define PCE_API_MINOR 2
+#define PCE_API_MINOR 3
 
 typedef struct pce_ctx pce_ctx;
 
@@ -294,7 +298,8 @@ int pce_whisper_align_fetch(pce_ctx *ctx, int32_t clip, int32_t *text_idx, int32
  * _enqueue queues the device-to-host copies behind the alignment on the context's stream into pinned staging memory and returns at
  * once (*n_clips, *path_stride = max rows + max columns of the batch: the row pitch of the index arrays); _wait blocks on those
  * copies only and writes path_len[n_clips] and the first path_len[i] entries of text_idx / time_idx [n_clips][path_stride] (either may
- * be NULL).  slot is 0 or 1 (two batches in flight).  The same indices as pce_whisper_align_fetch clip by clip. */
+ * be NULL).  slot is 0 or 1 (two batches in flight); _enqueue on a slot whose previous fetch has not been waited for is PCE_E_STATE (its
+ * copies may still be landing in the staging buffer).  The same indices as pce_whisper_align_fetch clip by clip. */
 int pce_whisper_align_paths_enqueue(pce_ctx *ctx, int32_t slot, int32_t *n_clips, int32_t *path_stride);
 int pce_whisper_align_paths_wait(pce_ctx *ctx, int32_t slot, int32_t *path_len, int32_t *text_idx, int32_t *time_idx);
 

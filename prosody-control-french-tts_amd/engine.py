@@ -738,11 +738,16 @@ _DEFAULT_ENGINE = None
 
 def get_default_engine(device: int = None) -> ProsodyEngine:
     """Process-wide engine used by the module-level drop-in functions (``Pipeline.compute_*``).  ONE context per process (the
-    reference's process owns one Whisper model on one GPU, config.yaml:58): ``device=None`` takes whatever engine exists (device 0
-    when none does); naming a device other than the existing engine's is an error rather than a silent run on the wrong GPU."""
+    reference's process owns one Whisper model on one GPU, config.yaml:58): ``device=None`` takes whatever engine exists -- when none
+    does, THIS RANK's device (``shard.local_device()``: ``LOCAL_RANK`` under a one-process-per-GPU launcher, 0 without one; a device-less
+    first caller such as ``Pipeline.compute_*`` must not pin rank 3 to GPU 0); naming a device other than the existing engine's is an
+    error rather than a silent run on the wrong GPU."""
     global _DEFAULT_ENGINE
     if _DEFAULT_ENGINE is None:
-        _DEFAULT_ENGINE = ProsodyEngine(0 if device is None else device)
+        if device is None:
+            from . import shard
+            device = shard.local_device()
+        _DEFAULT_ENGINE = ProsodyEngine(device)
     elif device is not None and getattr(_DEFAULT_ENGINE, "device", device) != device:
         raise RuntimeError(f"this process's engine lives on device {_DEFAULT_ENGINE.device}; device {device} was asked for "
                            "(one context per process: start one process per GPU, or close the engine first)")

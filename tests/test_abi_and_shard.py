@@ -30,7 +30,7 @@ def test_build_and_exports_match_header():
     exported = {ln.split()[-1] for ln in nm if ln.strip()}
     assert exported == declared, sorted(exported ^ declared)
     lib.pce_api_version.restype = ctypes.c_int
-    assert lib.pce_api_version() == 1 and lib.pce_api_minor() >= 2
+    assert lib.pce_api_version() == 1 and lib.pce_api_minor() >= 3
     lib.pce_kernel_name.restype = ctypes.c_char_p
     assert [lib.pce_kernel_name(i).decode() for i in range(len(E.KERNEL_IDS))] == E.KERNEL_IDS
     # struct layouts the ctypes side assumes
@@ -388,3 +388,56 @@ def test_default_engine_is_keyed_by_device():
             E.get_default_engine(0)
     finally:
         E.set_default_engine(None)
+
+
+_DEAD_PEER = r'''
+import os, sys, time
+rank, root, port = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+sys.path.insert(0, root)
+os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PCE_DIST_BACKEND="gloo",
+                  PCE_RANK_DEVICE="0", PCE_DIST_TIMEOUT_S="8")
+import torch
+torch.cuda.set_device = lambda d: None                      # (CPU-only container: the control plane is what is under test)
+import torch.distributed as dist
+from prosody_control_french_tts_amd import shard
+assert shard.collective_timeout_s() == 8
+r, w, dev = shard.init_from_env()
+assert (r, w, dev) == (rank, 2, 0)
+assert shard.barrier(True) is True                         # both ranks alive: the status barrier passes
+if rank == 1:
+    os._exit(7)                                            # this rank dies between two collectives, without a word
+t0 = time.time()
+try:
+    shard.barrier(True)
+    print("rank 0: the barrier returned although the peer is gone"); sys.exit(3)
+except Exception as e:                                     # gloo: connection reset at once, or the bounded wait
+    dt = time.time() - t0
+    print(f"rank 0 raised {type(e).__name__} after {dt:.1f} s")
+    sys.exit(0 if dt < 30.0 else 4)
+'''
+
+
+def test_a_dead_peer_ends_the_surviving_rank_within_the_collective_timeout(tmp_path):
+    """``shard.init_from_env`` bounds every collective (``PCE_DIST_TIMEOUT_S``): a rank whose peer has died raises inside its next status
+    barrier within the bound -- the reference's pool hands back ``(ok, name)`` per voice and ends (Code/audioPipeline.py:1111-1119, 1150-1154);
+    with the backend's default the survivor sat inside the barrier for 30 minutes (what took the driver's GPU run down in round 5)."""
+    script = tmp_path / "dead_peer.py"
+    script.write_text(_DEAD_PEER)
+    port = str(29250 + os.getpid() % 140)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), ROOT, port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=120)[0].decode())
+        except subprocess.TimeoutExpired:
+            p.kill(); outs.append("no result within 120 s: " + p.communicate()[0].decode())
+    assert procs[1].returncode == 7, outs[1][-2000:]
+    assert procs[0].returncode == 0 and "rank 0 raised" in outs[0], outs[0][-3000:]
+    with pytest.raises(ValueError):
+        os.environ["PCE_DIST_TIMEOUT_S"] = "0"
+        try:
+            from prosody_control_french_tts_amd import shard
+            shard.collective_timeout_s()
+        finally:
+            del os.environ["PCE_DIST_TIMEOUT_S"]

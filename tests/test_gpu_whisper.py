@@ -5,8 +5,12 @@ Tolerances: log-mel <= 2e-3 absolute in Whisper's (x+4)/4 units (fp32 DFT by 25x
 decomposition vs torch's FFT; values at the max-8 clamp agree to the same band); encoder
 output relative L2 error <= 2e-2 per clip and <= 6e-2 max-abs on unit-variance outputs
 (bf16 MFMA operands, fp32 accumulation and residual stream)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import whisper_oracle as WO
 from prosody_control_french_tts_amd import synth, whisper_weights as WW
@@ -162,6 +166,11 @@ def test_forced_alignment_matches_torch(engine, clips, width, heads):
             assert np.array_equal(pi[i, :pl[i]], res[i]["text_indices"]) and np.array_equal(pj[i, :pl[i]], res[i]["time_indices"])
     with pytest.raises(Exception):
         engine.whisper_align_paths_wait(0)
+    # a slot that still holds a fetch nobody waited for is refused (its copies may still be landing in the staging buffer), then usable again
+    engine.whisper_align_paths_enqueue(0)
+    with pytest.raises(Exception, match="still holds"):
+        engine.whisper_align_paths_enqueue(0)
+    assert np.array_equal(engine.whisper_align_paths_wait(0)[0], pl)
 
 
 def test_forced_alignment_matches_transformers_token_timestamps(engine, ops):
@@ -425,9 +434,9 @@ def test_cross_attention_from_the_encoder_output_against_the_kv_path_and_the_res
 
 @pytest.mark.parametrize("n", [130, 520])
 def test_frame_splits_of_the_encoder_output_cross_attention(n):
-    """The (clip, split) workgroups of ``k_xattn_absorbed`` come in 8 / 4 / 2 / 1 splits of the frames per clip (fewer than 128 / 256 / 512 clips, more):
-    the 4-split and the 1-split forms, which the other tests' batch sizes do not reach, against the K / V-form kernels on the same batch -- the same
-    tokens, log-probabilities within 0.02."""
+    """``k_xattn_absorbed`` runs 4 / 2 / 1 workgroups per clip (fewer than 256 / 512 clips, more; always the same four leaves of frames): the 4- and the
+    1-workgroup launches at batch sizes the other tests do not reach, against the K / V-form kernels on the same batch -- the same tokens, log-probabilities
+    within 0.02."""
     import os
     import prosody_control_french_tts_amd as P
     from tests.test_whisper_hf_crosscheck import _greedy_gold
@@ -467,6 +476,80 @@ def test_frame_splits_of_the_encoder_output_cross_attention(n):
         same += ta[i] == tb[i]
         assert ta[i] == ta[i % 13] and np.allclose(la[i], la[i % 13], atol=1e-6)      # the same recording decodes the same wherever it stands in the batch
     assert same >= 0.9 * n
+
+
+def test_a_clips_decoding_does_not_depend_on_the_batch_size():
+    """include/pce.h, minor 2: "a clip's Whisper results no longer depend on what it is batched with".  The encoder-output cross-attention runs 4 / 2 / 1
+    workgroups per clip by batch size (fewer than 256 / 512 clips, more; 8 / 4 / 2 / 1 in round 5); until round 6 each workgroup ran its own online softmax over its share of the
+    frames, so the partition -- and with it a clip's bits -- followed from the batch size.  Now the frames are always cut into the same four leaves
+    and merged in leaf order.  The same 13 recordings decoded alone, in a batch of 130, of 260 and of 520 (every workgroup count): IDENTICAL tokens and
+    log-probabilities, bit for bit (the next test forces the workgroup count at a fixed batch size)."""
+    import prosody_control_french_tts_amd as P
+    from tests.test_whisper_hf_crosscheck import _greedy_gold
+    from prosody_control_french_tts_amd.Aligners import decoding as DEC
+    _, rules = _greedy_gold()
+    edims = dict(n_mels=80, n_ctx=1500, n_state=128, n_head=2, n_layer=1)
+    tdims = dict(n_vocab=300, n_text_ctx=96, n_state=128, n_head=2, n_layer=2)
+    We, Wd = WW.synthetic_weights(edims, seed=277), WW.greedy_test_decoder_weights(tdims, seed=279)
+    base = [synth.synth_clip(80 + i, seconds=1.0 + 0.25 * (i % 5)) for i in range(13)]
+    init = _greedy_gold()[0]["initial"].tolist()
+
+    def decode(n):
+        eng = P.ProsodyEngine(0)
+        try:
+            eng.upload([base[i % 13] for i in range(n)], 16000); eng.logmel_run(80)
+            eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
+            eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+            return DEC.decode_batch(eng, tdims["n_vocab"], [list(init)] * n, [len(init)] * n, rules, sample_len=8)[:2]
+        finally:
+            eng.close()
+
+    ref_t, ref_l = decode(13)                                # 4 workgroups per clip
+    assert len({np.asarray(x, dtype=np.float32).tobytes() for x in ref_l}) > 6      # (the recordings really decode differently: their log-probabilities do)
+    for n in (1, 130, 260, 520):                             # 4, 4, 2, 1 workgroups per clip
+        t, l = decode(n)
+        for i in range(n):
+            assert t[i] == ref_t[i % 13], (n, i, t[i], ref_t[i % 13])
+            assert np.asarray(l[i], dtype=np.float32).tobytes() == np.asarray(ref_l[i % 13], dtype=np.float32).tobytes(), (n, i, l[i], ref_l[i % 13])
+
+
+@pytest.mark.parametrize("d,heads", [(128, 2), (768, 12), (1024, 16)])
+def test_cross_attention_bits_do_not_depend_on_the_workgroups_per_clip(d, heads, tmp_path):
+    """The same decode with 4, 2 and 1 workgroups per clip forced at one batch size (``PCE_XATTN_WPC``, read once per process: fresh processes), at the
+    head sizes of Whisper tiny-like, small and medium: tokens and log-probabilities bit-identical."""
+    import subprocess, sys
+    script = tmp_path / "wpc.py"
+    script.write_text(f"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, {ROOT!r})
+import prosody_control_french_tts_amd as P
+from prosody_control_french_tts_amd import synth, whisper_weights as WW
+from prosody_control_french_tts_amd.Aligners import decoding as DEC
+from tests.test_whisper_hf_crosscheck import _greedy_gold
+_, rules = _greedy_gold()
+init = _greedy_gold()[0]["initial"].tolist()
+edims = dict(n_mels=80, n_ctx=1500, n_state={d}, n_head={heads}, n_layer=1)
+tdims = dict(n_vocab=300, n_text_ctx=96, n_state={d}, n_head={heads}, n_layer=2)
+We, Wd = WW.synthetic_weights(edims, seed=31), WW.greedy_test_decoder_weights(tdims, seed=33)
+use = [synth.synth_clip(60 + i, seconds=1.5 + 0.5 * (i % 3)) for i in range(5)]
+with P.ProsodyEngine(0) as eng:
+    eng.upload(use, 16000); eng.logmel_run(80)
+    eng.whisper_load(edims, WW.pack(We, edims)); eng.whisper_encode_run()
+    eng.whisper_decoder_load(tdims, WW.pack_decoder(Wd, tdims))
+    t, l = DEC.decode_batch(eng, 300, [list(init)] * 5, [len(init)] * 5, rules, sample_len=6)[:2]
+h = hashlib.sha1()
+for a, b in zip(t, l):
+    h.update(np.asarray(a, dtype=np.int64).tobytes()); h.update(np.asarray(b, dtype=np.float32).tobytes())
+print("HASH", h.hexdigest(), [len(a) for a in t])
+""")
+    seen = {}
+    for wpc in (4, 2, 1):
+        env = dict(os.environ, PCE_XATTN_WPC=str(wpc))
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        seen[wpc] = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0]
+    assert len(set(seen.values())) == 1, seen
 
 
 def test_one_context_decodes_models_of_different_widths_in_turn(engine):
