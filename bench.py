@@ -137,11 +137,14 @@ def cpu_prosody_baseline(clips, rate, budget_clips):
     return out
 
 
-def cpu_whisper_baseline(clips, rate, model, W_enc, W_dec, dims, tdims, align_tokens, sot_len, budget_s=15.0, max_clips=4):
+def cpu_whisper_baseline(clips, rate, model, W_enc, W_dec, dims, tdims, align_tokens, sot_len, budget_s=15.0, max_clips=4, threads=None):
     """C3 leg of the CPU port: log-mel, the audio encoder and the forced alignment of the same clips through the
-    float32 restatement (oracle/whisper_oracle.py, torch CPU kernels on torch's intra-op threads), bounded by time."""
+    float32 restatement (oracle/whisper_oracle.py, torch CPU kernels on torch's intra-op threads), bounded by time.
+    ``threads``: the intra-op threads to use -- the prosody leg's worker count, so that ONE core count describes the composite."""
     import torch
     from oracle import whisper_oracle as WO
+    if threads:
+        torch.set_num_threads(int(threads))
     threads = torch.get_num_threads()
     t0 = time.perf_counter()
     done = 0
@@ -281,9 +284,11 @@ def run_rank(args, world, rank, local_rank):
     if world == 1 and rank == 0 and args.cpu_clips > 0:
         cpu = cpu_prosody_baseline(clips, rate, args.cpu_clips)
         if wdims:
-            wh = cpu_whisper_baseline(clips, rate, args.whisper_model, W_enc, W_dec, wdims, tdims, align_tokens, sot_len)
-            # both legs on ALL host cores, side by side (never one leg on one thread added to the other on 128): the prosody leg as
-            # utterance-parallel worker processes, the Whisper leg on torch's intra-op threads; the one-thread prosody rate stays beside them
+            wh = cpu_whisper_baseline(clips, rate, args.whisper_model, W_enc, W_dec, wdims, tdims, align_tokens, sot_len,
+                                      threads=(cpu.get("all_cores", {}).get("processes") or None))
+            # both legs on the SAME number of host cores, side by side (never one leg on one thread added to the other on 128, nor 64 processes beside
+            # 128 threads under one "cores" figure): the prosody leg as utterance-parallel worker processes, the Whisper leg on as many torch intra-op
+            # threads; the one-thread prosody rate stays beside them
             ac = cpu.get("all_cores", {})
             pros_rate = ac.get("value") or cpu["value"]
             pros_cores = ac.get("processes") or 1
@@ -292,7 +297,7 @@ def run_rank(args, world, rank, local_rank):
                            "prosody_one_thread": {"value": cpu["value"], "unit": "audio-seconds/sec", "cores": 1},
                            "whisper": dict(wh, value=args.seconds / wh["seconds_per_clip"], unit="audio-seconds/sec", cores=wh["threads"])}
             cpu["value"] = args.seconds / per_clip
-            cpu["cores"] = max(pros_cores, wh["threads"])
+            cpu["cores"] = pros_cores if pros_cores == wh["threads"] else {"prosody": pros_cores, "whisper": wh["threads"]}    # (one count: both legs run on the same number of cores)
             cpu["sample"] = (f"C3 per-clip time = prosody leg ({cpu['clips']} clips, C oracle, {pros_cores} worker processes: {pros_rate:.0f} x real time) + Whisper leg "
                              f"({wh['clips']} clips, {wh['seconds']:.1f} s, torch CPU float32 on {wh['threads']} threads: {args.seconds / wh['seconds_per_clip']:.2f} x real time); "
                              f"each leg uses the host's cores its own way, `legs` has them side by side; {cpu['seconds'] + wh['seconds']:.1f} s of CPU work")

@@ -174,7 +174,7 @@ void pce_destroy(pce_ctx *c)
                       &c->lu_energy, &c->lu_zbuf, &c->lu_out, &c->lu_en_work, &c->lu_en_acc,
                       &c->pi_meta, &c->pi_window, &c->pi_windowR, &c->pi_work, &c->pi_cand, &c->pi_gpeak,
                       &c->pi_psi, &c->pi_f0, &c->pi_strength, &c->pi_summary, &c->pi_peakwork, &c->pi_acc, &c->pi_rr, &c->pi_items, &c->pi_tw, &c->pi_dl, &c->pi_runs, &c->pi_fslice, &c->pi_blob,
-                      &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work,
+                      &c->st_out, &c->st_max, &c->st_off, &c->st_window, &c->st_twiddle, &c->st_work, &c->st_stage,
                       &c->fr_doff, &c->fr_sum, &c->fr_cnt,
                       &c->py_doff, &c->py_tab, &c->py_hdr, &c->py_bin, &c->py_lp, &c->py_ptr, &c->py_states};
     for (auto b : bufs) b->release();

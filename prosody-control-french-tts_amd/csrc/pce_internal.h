@@ -119,10 +119,11 @@ struct pce_ctx {
     std::vector<double> pi_t1;
 
     // stft
-    DevBuf st_out, st_max, st_off, st_window, st_twiddle, st_work;
+    DevBuf st_out, st_max, st_off, st_window, st_twiddle, st_work, st_stage;   // st_stage: one clip's finished values on their way to the host (pce_stft_db_fetch)
     int32_t st_nfft = 0, st_hop = 0;
     int64_t st_n_tiles = 0;
     bool st_ran = false;
+    bool st_final = false;            // st_out holds finished values (ref = max applied): after the two-FFT form or pce_stft_db_device; raw dB + st_max otherwise
     std::vector<int64_t> st_off_host;   // float offsets per clip (n_clips+1)
     std::vector<int32_t> st_frames;
 

@@ -308,20 +308,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_stft_raw(const int16_t *__restri
         for (int k = r0; k < NBINS; k += ROWS_PER_IT) o[(int64_t)k * cl.n_frames + fr] = tile[k][fr];
 }
 
-__global__ __launch_bounds__(256) void k_stft_norm(const StClip *__restrict__ clips, const unsigned int *__restrict__ clip_max,
-                                                  float amin2, float top_db, float *__restrict__ out)
+// ref = max / -80 dB floor of clips clip0 .. clip0 + gridDim.y - 1, from `src` (raw dB as k_stft_raw wrote them) to `dst` (dst == src: in place; a staging
+// buffer: dst_rebase = the first clip's offset, so that the clip lands at the start of the buffer)
+__global__ __launch_bounds__(256) void k_stft_norm(const StClip *__restrict__ clips, int clip0, const unsigned int *__restrict__ clip_max,
+                                                  float amin2, float top_db, const float *src, float *dst, int64_t dst_rebase)
 {
-    const StClip cl = clips[blockIdx.y];
-    const float ref = __uint_as_float(clip_max[blockIdx.y]);
+    const StClip cl = clips[clip0 + blockIdx.y];
+    const float ref = __uint_as_float(clip_max[clip0 + blockIdx.y]);
     const float ref_db = 10.0f * log10f(fmaxf(amin2, ref * ref));
     const float floor_db = 0.0f - top_db;
-    float *o = out + cl.out_off;
+    const float *in = src + cl.out_off;
+    float *o = dst + (cl.out_off - dst_rebase);
     const int64_t count = (int64_t)NBINS * cl.n_frames;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += 4 * stride) {
         float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int64_t j = i + q * stride; v[q] = j < count ? o[j] : 0.f; }
+        for (int q = 0; q < 4; q++) { const int64_t j = i + q * stride; v[q] = j < count ? in[j] : 0.f; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int64_t j = i + q * stride;
@@ -341,7 +344,7 @@ int pce_stft_db_run(pce_ctx *c, int32_t n_fft, int32_t hop)
     if (n_fft != NFFT) return pce_fail(c, PCE_E_LIMIT, "n_fft %d unsupported (the engine implements the reference's n_fft=1024)", n_fft);
     if (hop <= 0 || hop > NFFT) return pce_fail(c, PCE_E_INVALID, "bad hop %d", hop);
     PCE_HIP(c, hipSetDevice(c->device));
-    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }       // the previous run's normalisation still owns the output
+    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }       // (a lazy normalisation of the previous run, if one is still in flight)
     constexpr int F = 16, WAVES = 4;
     if (c->st_nfft != n_fft || c->st_hop != hop) {
         const int32_t n = c->n_clips;
@@ -407,15 +410,12 @@ int pce_stft_db_run(pce_ctx *c, int32_t n_fft, int32_t hop)
                                c->st_work.as<StTile>(), nt, (int)hop, c->st_window.as<float>(), g512, g1024, c->st_max.as<unsigned int>(),
                                1e-10f, c->st_out.as<float>());
         }
-        hipStream_t ss = c->stream;
-        { int rc = pce_side_begin(c, pce_ctx::SIDE_STFT, &ss); if (rc) return rc; }
-        if (c->n_clips > 0) {
-            KernelTimer t(c, PCE_K_STFT_NORM, ss);
-            hipLaunchKernelGGL(k_stft_norm, dim3(64, (unsigned)c->n_clips), dim3(256), 0, ss, c->st_off.as<StClip>(), c->st_max.as<unsigned int>(),
-                               1e-10f, 80.0f, c->st_out.as<float>());
-        }
-        { int rc = pce_side_end(c, pce_ctx::SIDE_STFT, ss); if (rc) return rc; }
+        // Round 6: NO second pass here.  `ref=np.max` / the -80 dB floor re-read and re-wrote the whole matrix (2.7 x the stage's algorithmic bytes in the
+        // PMC pass of round 5: written raw, read, rewritten).  The matrix stays as k_stft_raw wrote it -- 10 log10(max(amin^2, |X|^2)), one write -- beside
+        // the clip's maximum, and whoever takes the values applies `max(x - ref_db, -80)`: pce_stft_db_fetch per clip on its way out, pce_stft_db_device once,
+        // in place, when a device-side consumer asks for the finished matrix.  Same kernel, same arithmetic, same bits as the eager pass.
     }
+    c->st_final = c->stft_two_fft;
     PCE_HIP(c, hipGetLastError());
     c->st_ran = true;
     return PCE_OK;
@@ -439,7 +439,17 @@ int pce_stft_db_fetch(pce_ctx *c, int32_t clip, float *out)
     PCE_HIP(c, hipSetDevice(c->device));
     { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }
     const int64_t off = c->st_off_host[(size_t)clip], cnt = c->st_off_host[(size_t)clip + 1] - off;
-    PCE_HIP(c, hipMemcpyAsync(out, c->st_out.as<float>() + off, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+    const float *src = c->st_out.as<float>() + off;
+    if (!c->st_final) {
+        // the consumer's half of the stage: this clip's `x - ref_db`, floored at -80 dB, on its way out (through a staging buffer: the resident matrix stays raw)
+        PCE_HIP(c, c->st_stage.reserve(sizeof(float) * (size_t)cnt + 64));
+        KernelTimer t(c, PCE_K_STFT_NORM);
+        hipLaunchKernelGGL(k_stft_norm, dim3(64, 1), dim3(256), 0, c->stream, c->st_off.as<StClip>(), (int)clip, c->st_max.as<unsigned int>(), 1e-10f, 80.0f,
+                           c->st_out.as<float>(), c->st_stage.as<float>(), off);
+        PCE_HIP(c, hipGetLastError());
+        src = c->st_stage.as<float>();
+    }
+    PCE_HIP(c, hipMemcpyAsync(out, src, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
     PCE_HIP(c, hipStreamSynchronize(c->stream));
     pce_profile_collect(c);
     return PCE_OK;
@@ -449,7 +459,16 @@ int pce_stft_db_device(pce_ctx *c, const void **d_ptr, int64_t *bytes)
 {
     if (!c) return PCE_E_INVALID;
     if (!c->st_nfft || !c->st_ran) return pce_fail(c, PCE_E_STATE, "pce_stft_db_device before pce_stft_db_run");
-    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }   // work queued on the context's stream after this call sees the final values
+    { int rc = pce_side_join(c, pce_ctx::SIDE_STFT); if (rc) return rc; }
+    if (!c->st_final && c->n_clips > 0) {
+        // a device-side consumer wants the finished matrix: normalise once, in place, on the context's stream (work queued behind this call sees the final values)
+        PCE_HIP(c, hipSetDevice(c->device));
+        KernelTimer t(c, PCE_K_STFT_NORM);
+        hipLaunchKernelGGL(k_stft_norm, dim3(64, (unsigned)c->n_clips), dim3(256), 0, c->stream, c->st_off.as<StClip>(), 0, c->st_max.as<unsigned int>(), 1e-10f, 80.0f,
+                           c->st_out.as<float>(), c->st_out.as<float>(), (int64_t)0);
+        PCE_HIP(c, hipGetLastError());
+        c->st_final = true;
+    }
     if (d_ptr) *d_ptr = c->st_out.p;
     if (bytes) *bytes = (int64_t)sizeof(float) * c->st_off_host[(size_t)c->n_clips];
     return PCE_OK;
