@@ -45,7 +45,7 @@ extern "C" {
  * cross-attention of a decoding step always cuts a clip's frames into the same four ranges (minor 2's promise now holds for every batch size: the
  * round-5 kernel cut them by the number of workgroups per clip, which followed the batch size), pce_whisper_align_paths_enqueue on a slot that
  * still holds an un-waited fetch is PCE_E_STATE, and no kernel carries the packed fp32 operand selection that returns wrong lanes beside MFMA waves
- * of other streams / contexts / processes (results no longer depend on what else runs on the device: tools/isa_guard.py). */
+ * of other streams / contexts / processes (results no longer depend on what else runs on the device: tools/isa_guard.py); pce_selftest_xattn. */
 #define PCE_API_VERSION 1
 #define PCE_API_MINOR 3
 
@@ -268,6 +268,15 @@ int pce_selftest_gemm(pce_ctx *ctx, const uint16_t *A, const uint16_t *B, const 
  * path only.  *fell_back (may be NULL): number of workgroups that had to take the exact path (mode 0). */
 int pce_selftest_attention(pce_ctx *ctx, const uint16_t *q, const uint16_t *k, const uint16_t *v, int32_t clips, int32_t heads, int32_t q_len,
                            int32_t k_len, int32_t causal, int32_t mode, uint16_t *out, int32_t *fell_back);
+/* Self-test of the cross-attention of an incremental decoding step from the ENCODER OUTPUT (csrc/pce_xattn.inc: LayerNorm + query projection + Q' = q Wk,
+ * one streaming pass over E with an online softmax per leaf of frames, the merge tree, out = Wv U + bv) for ONE layer on host arrays: resid [n][d] fp32,
+ * ln_w / ln_b / bq / bv [d] fp32, wq / wk / wv [d][d] and E [n][k_cap][d] as 16-bit patterns of the context's operand type (rows of the weights = output
+ * features; Whisper's key projection has no bias), k_len[n] valid frames per clip.  d in {128, 256, 384, 512, 768, 1024}, heads = d / 64.
+ * workgroups_per_clip: 0 = what the batch size selects, or 1 / 2 / 4 -- the result must not depend on it (the frames are always cut into the same four
+ * leaves and merged in the same tree).  out [n][d]: 16-bit patterns. */
+int pce_selftest_xattn(pce_ctx *ctx, const float *resid, const float *ln_w, const float *ln_b, const uint16_t *wq, const float *bq, const uint16_t *wk,
+                       const uint16_t *wv, const float *bv, const uint16_t *E, const int32_t *k_len, int32_t n, int32_t k_cap, int32_t d, int32_t heads,
+                       int32_t workgroups_per_clip, uint16_t *out);
 int pce_whisper_encode_fetch(pce_ctx *ctx, int32_t clip, float *out /* [1500][n_state] */);
 
 /* ---- R8: forced alignment of known text tokens (teacher-forced decoder + cross-attention DTW) ----

@@ -14,6 +14,7 @@ PCE_BOTH(int, pce_whisper_encode_run, (pce_ctx *))
 PCE_BOTH(int, pce_whisper_encode_fetch, (pce_ctx *, int32_t, float *))
 PCE_BOTH(int, pce_selftest_attention, (pce_ctx *, const uint16_t *, const uint16_t *, const uint16_t *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, uint16_t *, int32_t *))
 PCE_BOTH(int, pce_selftest_gemm, (pce_ctx *, const uint16_t *, const uint16_t *, const float *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, uint16_t *))
+PCE_BOTH(int, pce_selftest_xattn, (pce_ctx *, const float *, const float *, const float *, const uint16_t *, const float *, const uint16_t *, const uint16_t *, const float *, const uint16_t *, const int32_t *, int32_t, int32_t, int32_t, int32_t, int32_t, uint16_t *))
 PCE_BOTH(int, pce_whisper_decoder_load, (pce_ctx *, const pce_whisper_text_dims *, const float *, int64_t))
 PCE_BOTH(int, pce_whisper_align_run, (pce_ctx *, const int32_t *, const int32_t *, const int32_t *, int32_t, const uint8_t *, int32_t, float))
 PCE_BOTH(int, pce_whisper_align_fetch, (pce_ctx *, int32_t, int32_t *, int32_t *, int32_t *, double *))
@@ -60,6 +61,11 @@ int pce_selftest_gemm(pce_ctx *c, const uint16_t *A, const uint16_t *B, const fl
                       int32_t vt_sp, uint16_t *out)
 {
     return PCE_FWD(pce_selftest_gemm, c, A, B, bias, M, N, K, epilogue, rows_per_clip, vt_sp, out);
+}
+int pce_selftest_xattn(pce_ctx *c, const float *resid, const float *ln_w, const float *ln_b, const uint16_t *wq, const float *bq, const uint16_t *wk, const uint16_t *wv,
+                       const float *bv, const uint16_t *E, const int32_t *k_len, int32_t n, int32_t k_cap, int32_t d, int32_t heads, int32_t workgroups_per_clip, uint16_t *out)
+{
+    return PCE_FWD(pce_selftest_xattn, c, resid, ln_w, ln_b, wq, bq, wk, wv, bv, E, k_len, n, k_cap, d, heads, workgroups_per_clip, out);
 }
 int pce_whisper_decoder_load(pce_ctx *c, const pce_whisper_text_dims *dims, const float *weights, int64_t n_floats)
 {

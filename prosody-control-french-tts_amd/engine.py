@@ -111,7 +111,7 @@ EXPORTS = ["pce_create", "pce_destroy", "pce_last_error", "pce_sync", "pce_api_v
            "pce_pitch_plan", "pce_pitch_run", "pce_pitch_set_refine", "pce_pitch_fetch",
            "pce_stft_db_run", "pce_stft_db_shape", "pce_stft_db_fetch", "pce_stft_db_device",
            "pce_resample_run", "pce_download_pcm_s16",
-           "pce_dtw", "pce_nw_align", "pce_levenshtein", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_align_paths_enqueue", "pce_whisper_align_paths_wait", "pce_whisper_sample_keys", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands",
+           "pce_dtw", "pce_nw_align", "pce_levenshtein", "pce_whisper_decoder_load", "pce_whisper_align_run", "pce_whisper_align_shape", "pce_whisper_align_fetch", "pce_whisper_align_paths_enqueue", "pce_whisper_align_paths_wait", "pce_whisper_sample_keys", "pce_whisper_decode_step", "pce_whisper_decode_step_ex", "pce_whisper_decode_loop", "pce_whisper_set_operands", "pce_whisper_get_operands", "pce_selftest_xattn",
            "pce_logmel_run", "pce_logmel_run_at", "pce_logmel_fetch", "pce_whisper_load", "pce_whisper_encode_run", "pce_selftest_gemm", "pce_selftest_attention", "pce_whisper_encode_fetch",
            "pce_stats_enqueue", "pce_stats_wait", "pce_bert_load", "pce_bert_run", "pce_bert_fetch",
            "pce_profile_enable", "pce_profile_reset", "pce_profile_get", "pce_profile_get_work", "pce_kernel_name"]
@@ -182,6 +182,7 @@ def load_library() -> C.CDLL:
     lib.pce_whisper_encode_run.argtypes = [vp]
     lib.pce_selftest_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.pce_selftest_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.pce_selftest_xattn.argtypes = [vp] * 11 + [i32] * 5 + [vp]
     lib.pce_whisper_encode_fetch.argtypes = [vp, i32, vp]
     lib.pce_profile_enable.argtypes = [vp, C.c_int]
     lib.pce_profile_reset.argtypes = [vp]
@@ -499,6 +500,24 @@ class ProsodyEngine:
                                                      tv.view(torch.int16).numpy().ctypes.data, clips, hd // 64, q_len, k_len, int(bool(causal)), int(mode),
                                                      out.view(torch.int16).numpy().ctypes.data, C.addressof(fb)))
         return out.float().numpy(), int(fb.value)
+
+    def selftest_xattn(self, resid, ln_w, ln_b, wq, bq, wk, wv, bv, E, k_len, heads: int, workgroups_per_clip: int = 0):
+        """One layer of the encoder-output cross-attention of a decoding step (``pce_selftest_xattn``): resid [n][d], E [n][k_cap][d], weights [d][d]
+        float arrays (weights and E rounded to the context's operand type here) -> (out [n][d] float32 decoded from the 16-bit result, and the
+        ROUNDED wq / wk / wv / E as float32: what the kernels really multiplied, for an exact restatement)."""
+        import torch
+        dt = self._op_dtype()
+        r16 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dt).contiguous()
+        tq, tk, tv, tE = r16(wq), r16(wk), r16(wv), r16(E)
+        n, k_cap, d = tE.shape
+        f32 = lambda x: np.ascontiguousarray(x, dtype=np.float32)
+        res, lw, lb, vq, vv = f32(resid), f32(ln_w), f32(ln_b), f32(bq), f32(bv)
+        kl = np.ascontiguousarray(k_len, dtype=np.int32)
+        out = torch.zeros((n, d), dtype=dt)
+        ptr = lambda t: t.view(torch.int16).numpy().ctypes.data
+        self._check(self._lib.pce_selftest_xattn(self._ctx, res.ctypes.data, lw.ctypes.data, lb.ctypes.data, ptr(tq), vq.ctypes.data, ptr(tk), ptr(tv), vv.ctypes.data,
+                                                 ptr(tE), kl.ctypes.data, int(n), int(k_cap), int(d), int(heads), int(workgroups_per_clip), ptr(out)))
+        return out.float().numpy(), tq.float().numpy(), tk.float().numpy(), tv.float().numpy(), tE.float().numpy()
 
     def whisper_encode_fetch(self, clip: int) -> np.ndarray:
         out = np.zeros((1500, self._wdims.n_state), dtype=np.float32)

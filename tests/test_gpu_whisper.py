@@ -554,6 +554,57 @@ print("HASH", h.hexdigest(), [len(a) for a in t])
     assert len(set(seen.values())) == 1, seen
 
 
+@pytest.mark.parametrize("d", [128, 256, 384, 512, 768, 1024])
+def test_encoder_output_cross_attention_against_a_float64_restatement(engine, d):
+    """One layer of the cross-attention of a decoding step (``k_xq_fused`` -> ``k_xattn_absorbed`` -> ``k_uv_absorb``) on its own, for every width it is
+    built for and every workgroup count per clip (the decode-level tests allow 0.02 in a log-probability; a systematic error of a few 1e-3 in
+    one head -- the unrounded K / V, a hi / lo split mistake -- would pass them).  The restatement is float64 on the values the kernels really multiply
+    (16-bit weights and E; the LayerNorm output and the query rounded to 16 bits where the reference's fp16 Linear rounds them): what is left is the
+    rounding of Q' = q Wk, of the probabilities and of U to hi + lo pairs (2^-22) and of the OUTPUT to 16 bits, so the bound is one 16-bit step of the
+    output plus 1e-3 of its scale; the bits must not depend on the workgroup count (1, 2, 4) nor on the batch (the first clips alone)."""
+    engine.whisper_set_operands("fp16")
+    heads = d // 64
+    rng = np.random.default_rng(1000 + d)
+    n, k_cap = 5, 1500
+    k_len = np.array([1500, 1499, 700, 33, 1], dtype=np.int32)
+    resid = rng.standard_normal((n, d)).astype(np.float32) * 1.5 + 0.2
+    ln_w = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32); ln_b = (0.05 * rng.standard_normal(d)).astype(np.float32)
+    sc = 1.0 / np.sqrt(d)
+    wq, wk, wv = (rng.standard_normal((d, d)).astype(np.float32) * sc * g for g in (1.6, 1.6, 1.0))
+    bq, bv = (0.1 * rng.standard_normal(d)).astype(np.float32), (0.1 * rng.standard_normal(d)).astype(np.float32)
+    E = rng.standard_normal((n, k_cap, d)).astype(np.float32)
+    E[:, :, : d // 2] += rng.standard_normal((n, 1, d // 2)).astype(np.float32)          # (a per-clip offset: the attention is not uniform)
+    outs = {}
+    for wpc in (4, 2, 1, 0):
+        outs[wpc], rq, rk, rv, rE = engine.selftest_xattn(resid, ln_w, ln_b, wq, bq, wk, wv, bv, E, k_len, heads, wpc)
+    for wpc in (2, 1, 0):
+        assert outs[wpc].tobytes() == outs[4].tobytes(), wpc
+    solo = engine.selftest_xattn(resid[:2], ln_w, ln_b, wq, bq, wk, wv, bv, E[:2], k_len[:2], heads, 0)[0]
+    assert solo.tobytes() == outs[4][:2].tobytes()
+    # float64 restatement
+    r16 = lambda x: x.astype(np.float16).astype(np.float64)
+    x = resid.astype(np.float64)
+    mu = x.mean(axis=1, keepdims=True); var = ((x - mu) ** 2).mean(axis=1, keepdims=True)
+    ln = r16((x - mu) / np.sqrt(var + 1e-5) * ln_w + ln_b)                                # the kernel parks the LayerNorm output as op_t
+    q = r16(ln @ rq.astype(np.float64).T + bq)                                            # rounded as the reference's fp16 Linear does
+    want = np.zeros((n, d))
+    for c in range(n):
+        Ec = rE[c, : k_len[c]].astype(np.float64)
+        for h in range(heads):
+            sl = slice(64 * h, 64 * h + 64)
+            kh = Ec @ rk[sl].astype(np.float64).T                                         # [t][64]   (never rounded: the kernels fold Wk into the query)
+            s_ = (kh @ q[c, sl]) * 0.125
+            p = np.exp(s_ - s_.max()); p /= p.sum()
+            u = p @ Ec                                                                    # [d]
+            want[c, sl] = rv[sl].astype(np.float64) @ u + bv[sl]
+    got = outs[4].astype(np.float64)
+    scale = np.abs(want).max()
+    err = np.abs(got - want)
+    assert np.all(err <= np.abs(want) * 2.0 ** -10 + 1.0e-3 * scale), (d, float(err.max()), float(scale))
+    assert np.sqrt(np.mean(err ** 2)) <= 4.0e-4 * scale, (d, float(np.sqrt(np.mean(err ** 2))), float(scale))
+    engine.whisper_set_operands("fp16-resid16")
+
+
 def test_one_context_decodes_models_of_different_widths_in_turn(engine):
     """``k_xattn_absorbed<d, slots>`` is one function per width, each with its own dynamic-LDS attribute (68 KB at d = 1024: above the default
     limit): a context that has decoded with one width must still be able to decode with another (the attribute is tracked per instantiation)."""
