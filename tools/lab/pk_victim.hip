@@ -105,6 +105,24 @@ __global__ __launch_bounds__(256) void k_victim(Report *rep, int *nrep, int reps
                 w = t;
             }
             res = re * re + im * im;
+        } else if (CLS >= 27 && CLS <= 31) {
+            // packed 16-bit forms (two halves of ONE 32-bit register): is the op_sel:[0,1] effect a property of the 64-bit packed fp32 path only?
+            unsigned x = 0x3C003C00u + (unsigned)(lane & 7) + (((unsigned)(lane & 3)) << 16), w = 0x3BFF3C01u, acc = 0u;     // (1 + small, 1 + small), (1 - 2^-11.., 1 + 2^-10)
+            asm volatile("" : "+v"(x), "+v"(w));
+#pragma unroll
+            for (int k = 0; k < 64; k++) {
+                unsigned d;
+                if (CLS == 27)      asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(w));
+                else if (CLS == 28) asm volatile("v_pk_add_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(x), "v"(w));
+                else if (CLS == 29) asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(w), "v"(acc));
+                else if (CLS == 30) asm volatile("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(w));
+                else                asm volatile("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(w));
+                acc = (acc << 1 | acc >> 31) ^ d;
+                asm volatile("" : "+v"(acc));
+                x = (CLS == 28) ? (d & 0x3FFF3FFFu) | 0x3C003C00u : d;
+                if (CLS >= 30) x = (d & 0x0FFF0FFFu) | 0x00010001u;
+            }
+            res = __uint_as_float((acc & 0x007FFFFFu) | 0x3F800000u);
         } else if (CLS >= 8) {
             // ONE packed instruction form per class, written in assembly: which encoding is it?
             f2 x = {0.5f + 0.001f * lane + seed, 0.25f - 0.002f * lane}, w = {1.0009765625f, 0.9990234375f}, acc = {0.f, 0.f};
@@ -125,6 +143,13 @@ __global__ __launch_bounds__(256) void k_victim(Report *rep, int *nrep, int reps
                 else if (CLS == 18) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(w));               // src0 hi to both, src1 swapped
                 else if (CLS == 19) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(d) : "v"(x), "v"(w));  // src0 swapped add
                 else if (CLS == 20) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(d) : "v"(x), "v"(w));               // both swapped
+                else if (CLS == 32 || CLS == 33) {                                    // v_pk_mov_b32 with the other selections, then a plain multiply
+                    f2 t;
+                    if (CLS == 32) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(t) : "v"(w), "v"(x));
+                    else           asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(t) : "v"(w), "v"(x));
+                    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(t));
+                    d[0] = d[0] * 0.5f + 0.25f; d[1] = d[1] * 0.5f + 0.25f;
+                }
                 else if (CLS == 21) { f2 t; asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(t) : "v"(w)); asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(t)); }   // swap by v_pk_mov_b32, plain multiply
                 else if (CLS == 23) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(x), "v"(w), "v"(acc));    // src2 swapped
                 else if (CLS == 24) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "v"(w), "v"(acc));    // src0 swapped
@@ -176,9 +201,9 @@ __global__ __launch_bounds__(256) void k_victim(Report *rep, int *nrep, int reps
 
 int main(int argc, char **argv)
 {
-    const char *names[] = {"pkfma", "fma32", "fma64", "lds64", "lds32", "dft", "cmul", "ldsdiv", "mul_sel01_hi10", "mul_hi10", "add_neg", "add_sel01_hi10", "fma_sel", "mul_plain", "mul_sel10", "add_neglo", "mul_src0swap", "mul_src1hi", "mul_cmul2", "add_src0swap", "mul_bothswap", "pkmov_swap", "vmov_swap", "fma_src2swap", "fma_src0swap", "mul_hi01", "fma_src02swap"};
+    const char *names[] = {"pkfma", "fma32", "fma64", "lds64", "lds32", "dft", "cmul", "ldsdiv", "mul_sel01_hi10", "mul_hi10", "add_neg", "add_sel01_hi10", "fma_sel", "mul_plain", "mul_sel10", "add_neglo", "mul_src0swap", "mul_src1hi", "mul_cmul2", "add_src0swap", "mul_bothswap", "pkmov_swap", "vmov_swap", "fma_src2swap", "fma_src0swap", "mul_hi01", "fma_src02swap", "pk_mul_f16_sel01", "pk_add_f16_sel01", "pk_fma_f16_sel01", "pk_mul_lo_u16_sel01", "pk_max_i16_sel01", "pkmov_sel01", "pkmov_sel11"};
     int cls = -1;
-    for (int i = 0; i < 27; i++) if (argc > 1 && !strcmp(argv[1], names[i])) cls = i;
+    for (int i = 0; i < 34; i++) if (argc > 1 && !strcmp(argv[1], names[i])) cls = i;
     if (cls < 0) { fprintf(stderr, "usage: pk_victim pkfma|fma32|fma64|lds64|lds32|dft [seconds] [same_process_mfma]\n"); return 2; }
     const double seconds = argc > 2 ? atof(argv[2]) : 20.0;
     const int same = argc > 3 ? atoi(argv[3]) : 0;
@@ -220,6 +245,13 @@ int main(int argc, char **argv)
                 case 24: hipLaunchKernelGGL(k_victim<24>, g, b, 0, sa, rep, nrep, 40, seed); break;
                 case 25: hipLaunchKernelGGL(k_victim<25>, g, b, 0, sa, rep, nrep, 40, seed); break;
                 case 26: hipLaunchKernelGGL(k_victim<26>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 27: hipLaunchKernelGGL(k_victim<27>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 28: hipLaunchKernelGGL(k_victim<28>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 29: hipLaunchKernelGGL(k_victim<29>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 30: hipLaunchKernelGGL(k_victim<30>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 31: hipLaunchKernelGGL(k_victim<31>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 32: hipLaunchKernelGGL(k_victim<32>, g, b, 0, sa, rep, nrep, 40, seed); break;
+                case 33: hipLaunchKernelGGL(k_victim<33>, g, b, 0, sa, rep, nrep, 40, seed); break;
                 default: hipLaunchKernelGGL(k_victim<5>, g, b, 0, sa, rep, nrep, 20, seed); break;
             }
             launches++;
