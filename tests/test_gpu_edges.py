@@ -224,8 +224,8 @@ def test_energy_chunks_per_workgroup_do_not_change_results(monkeypatch, cpb):
 
 @pytest.mark.gpu
 def test_stft_one_fft_and_two_fft_forms_agree_bitwise(engine, synth16k, monkeypatch):
-    """Default: one FFT pass writing unnormalised dB + an in-place normalisation pass on a side stream.
-    PCE_STFT_TWO_FFT=1: maximum pass, then the dB pass (each byte moved once).  Same float operations in the
+    """Default: one FFT pass writing unnormalised dB + the clip's maximum, normalised where the values are consumed (round 6; an eager in-place
+    pass on a side stream before).  PCE_STFT_TWO_FFT=1: maximum pass, then the dB pass (each byte moved once).  Same float operations in the
     same order on every bin: the matrices must be identical."""
     clips = synth16k
     monkeypatch.setenv("PCE_STFT_TWO_FFT", "1")
@@ -236,6 +236,38 @@ def test_stft_one_fft_and_two_fft_forms_agree_bitwise(engine, synth16k, monkeypa
     engine.upload(clips, 16000)
     engine.stft_db_run(1024, 256); engine.stft_db_run(1024, 256)        # a second run queued behind the first one's side-stream pass
     assert [engine.stft_db_fetch(i).tobytes() for i in range(len(clips))] == ref
+
+
+@pytest.mark.gpu
+def test_stft_db_is_finished_where_it_is_consumed(engine, synth16k, monkeypatch):
+    """Round 6: ``pce_stft_db_run`` leaves the matrix as the FFT pass wrote it (raw dB + the clip's maximum: one write instead of write, read,
+    rewrite); ``ref = max`` / the -80 dB floor are applied by whoever takes the values.  A fetch finishes ONE clip through a staging buffer and leaves
+    the resident matrix raw (fetching twice, in any order, gives the same bytes); ``pce_stft_db_device`` finishes the whole matrix once, in place, and
+    fetches after it read the finished values as they are.  All three are the two-FFT form's bytes."""
+    import ctypes as C
+    clips = synth16k
+    monkeypatch.setenv("PCE_STFT_TWO_FFT", "1")
+    with pkg.ProsodyEngine(0) as two:
+        two.upload(clips, 16000); two.stft_db_run(1024, 256)
+        ref = [two.stft_db_fetch(i) for i in range(len(clips))]
+    monkeypatch.delenv("PCE_STFT_TWO_FFT")
+    engine.upload(clips, 16000)
+    engine.stft_db_run(1024, 256)
+    order = [3, 0, 3, len(clips) - 1, 1, 0]
+    for i in order:                                             # lazy, per clip, repeatable
+        assert engine.stft_db_fetch(i).tobytes() == ref[i].tobytes(), i
+    ptr, nbytes = engine.stft_db_device()                       # the finished matrix for a device-side consumer
+    assert nbytes == 4 * sum(r.size for r in ref)
+    hip = C.CDLL("libamdhip64.so")
+    host = np.empty(nbytes // 4, dtype=np.float32)
+    engine.sync()
+    assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0        # hipMemcpyDeviceToHost
+    assert host.tobytes() == b"".join(r.tobytes() for r in ref)
+    ptr2, _ = engine.stft_db_device()                           # a second request does not normalise twice
+    assert ptr2 == ptr
+    for i in (0, len(clips) - 1, 2):
+        assert engine.stft_db_fetch(i).tobytes() == ref[i].tobytes(), i
+    assert (ref[0] <= 0.0).all() and ref[0].max() == 0.0 and ref[0].min() >= -80.0
 
 
 @pytest.mark.gpu
