@@ -53,3 +53,17 @@ def test_prosody_kernels_beside_the_encoder_of_other_processes():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if "iterations 400" in l]
     assert len(lines) == 3 and all(l.rstrip().endswith(": none") for l in lines), r.stdout[-3000:]
+
+
+def test_one_process_repeats_the_chain_300_times_bit_for_bit():
+    """The same chain in ONE fresh process, 300 repetitions: log-mel, encoder, the device-resident decoding loop (k_xq_fused, k_xattn_absorbed, k_uv_absorb,
+    k_self_attn1w and the few-row GEMMs: wave-level LDS hand-overs, hand-counted waits, ds_read_b64_tr_b16), alignment -- a race inside a kernel shows up here
+    without any neighbour."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PROBE_") and k != "HSA_CU_MASK"}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lab", "race_probe.py"), "300", "solo"], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("no result within 240 s\n" + str(e.stdout)[-2000:] + str(e.stderr)[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if "iterations 300" in l]
+    assert len(line) == 1 and line[0].rstrip().endswith(": none"), r.stdout[-3000:]
