@@ -81,6 +81,23 @@ def test_bench_two_ranks_one_device_records_equal_one_rank(tmp_path):
     assert abs(j2["value"] - 2 * 64 * 10.0 * 3 / (j2["ms_per_step"] * 3e-3)) <= 1e-6 * j2["value"]
 
 
+def test_bench_eight_ranks_one_device_records_equal_one_rank(tmp_path):
+    """BASELINE.json configs[3] runs EIGHT ranks with one all-gather of their statistics.  The same launcher, rank code and exchange with eight rank
+    processes on the one device (gloo): one JSON line with ``n_gpus`` 8, and the gathered records of the 8 x 64 clips equal a one-rank run's of the same
+    512 clips bit for bit -- eight engine contexts at once on one GPU (what the reference's worker pool does with five, config.yaml:57-58)."""
+    common = ["--workload", "c2", "--steps", "2", "--warmup", "1", "--cpu-clips", "0", "--streamed-steps", "0", "--framing-clips", "0"]
+    eight = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--clips", "64", "--dump-records", str(tmp_path / "w8.npy")] + common,
+                 _env(), "bench.py --gpus 8")
+    j8 = _json_line(eight, "bench.py --gpus 8")
+    assert j8["n_gpus"] == 8 and j8["dist_backend"] == "gloo" and j8["scaling"] == "weak" and j8["config"]["clips_per_gpu"] == 64 and j8["value"] > 0
+    one = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "512", "--dump-records", str(tmp_path / "w1.npy")] + common,
+               _env(), "bench.py --gpus 1")
+    assert _json_line(one, "bench.py --gpus 1")["n_gpus"] == 1
+    r8, r1 = np.load(tmp_path / "w8.npy"), np.load(tmp_path / "w1.npy")
+    assert r8.shape == r1.shape == (512, 7) and r8.tobytes() == r1.tobytes()
+    assert abs(j8["value"] - 8 * 64 * 10.0 * 2 / (j8["ms_per_step"] * 2e-3)) <= 1e-6 * j8["value"]      # value = all ranks' audio / the slowest rank's time
+
+
 _RCCL1 = r'''
 import json, os, sys
 import numpy as np
